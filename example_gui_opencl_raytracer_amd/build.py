@@ -1,0 +1,67 @@
+"""Build the native pieces in-tree (no JIT cache: the .so travels with the repo snapshot).
+
+  libopencl_wrap_hip.so  = hip_wrap.cpp (C-ABI shim) + whitted_fast.hip + whitted_strict.hip
+                           (gfx950 kernels) + scene_prep.c + png_codec.c
+Usage: python -m example_gui_opencl_raytracer_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libopencl_wrap_hip.so")
+ARCH = "gfx950"
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+CC = os.environ.get("CC") or "gcc"
+
+DEVICE_DEPS = ["whitted_trace.inc", "whitted_launch.inc", "whitted_params.h"]
+UNITS = [
+    # (source, compiler, flags, extra deps)
+    ("whitted_fast.hip", "hip", ["-O3", f"--offload-arch={ARCH}"], DEVICE_DEPS),
+    ("whitted_strict.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-ffp-contract=off"], DEVICE_DEPS),
+    ("hip_wrap.cpp", "hip", ["-O2", "-std=c++17", "-Wall"],
+     ["whitted_params.h", "scene_prep.h", "png_codec.h", "../../include/opencl_wrap.h", "../../include/hip_wrap_ext.h"]),
+    ("scene_prep.c", "c", ["-O2", "-std=c99", "-ffp-contract=off", "-Wall", "-Wextra"], ["scene_prep.h"]),
+    ("host_camera.c", "c", ["-O2", "-std=c99", "-ffp-contract=off", "-Wall", "-Wextra", "-D_DEFAULT_SOURCE"],
+     ["../../include/hip_wrap_ext.h", "../../include/opencl_wrap.h"]),
+    ("png_codec.c", "c", ["-O2", "-std=c99", "-Wall", "-Wextra"], ["png_codec.h"]),
+]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for src, kind, flags, deps in UNITS:
+        spath = os.path.join(CSRC, src)
+        opath = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objs.append(opath)
+        dpaths = [spath, __file__] + [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
+        if not force and not _newer(opath, dpaths):
+            continue
+        cmd = ([HIPCC] if kind == "hip" else [CC]) + flags + ["-fPIC", "-c", spath, "-o", opath]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    if force or _newer(LIB, objs):
+        cmd = [HIPCC, "-shared", "-o", LIB] + objs + ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

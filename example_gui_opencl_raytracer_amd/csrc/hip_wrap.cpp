@@ -1,0 +1,672 @@
+/*
+ * hip_wrap.cpp -- the C-ABI shim: the reference's six cl_wrap_* entry points
+ * (reference src/opencl_wrap.h:29-42, src/opencl_wrap.c:11-416) implemented over the HIP
+ * runtime and the precompiled gfx950 kernels of whitted_{fast,strict}.hip, plus the
+ * extension entry points of include/hip_wrap_ext.h.
+ *
+ * Same conventions as the reference: every failure prints "ERROR:\t<message>" on stdout
+ * and calls exit(1); every call returns with its work complete (unless the caller opted
+ * into async mode); single host thread.
+ *
+ * There is NO CPU fallback: without a HIP device cl_wrap_init fails exactly as the
+ * reference fails without an OpenCL GPU (opencl_wrap.c:31-34).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hip_wrap_ext.h"
+#include "png_codec.h"
+#include "scene_prep.h"
+#include "whitted_params.h"
+
+extern "C" hipError_t wt_fast_launch_trace(const whitted_params*, int, unsigned, size_t, hipStream_t);
+extern "C" hipError_t wt_fast_launch_raygen(const raygen_params*, hipStream_t);
+extern "C" hipError_t wt_strict_launch_trace(const whitted_params*, int, unsigned, size_t, hipStream_t);
+extern "C" hipError_t wt_strict_launch_raygen(const raygen_params*, hipStream_t);
+
+namespace {
+
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8 }; /* = WT_F_* of whitted_trace.inc */
+constexpr unsigned BLOCK = 256;       /* work-group size; also the reference's rounding unit (opencl_wrap.c:374) */
+constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
+constexpr int LDS_LEVELS = 3;
+
+[[noreturn]] void die(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    printf("ERROR:\t");
+    vprintf(fmt, ap);
+    printf("\n");
+    va_end(ap);
+    fflush(stdout);
+    exit(1);
+}
+
+#define HIP_OK(call, what)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) die("%s (%s)", what, hipGetErrorString(e_));        \
+    } while (0)
+
+enum KernelKind { K_RAYGEN = 0, K_RAYTRACER = 1 };
+
+struct RaygenArgs { /* snapshot of the eight by-value raygen arguments + the launch range */
+    float corner[3], origin[3], up[3], right[3];
+    float w_factor, h_factor;
+    uint32_t width, height;
+    uint64_t id_offset;
+    uint32_t n_items;
+};
+
+struct Buffer {
+    void* dptr = nullptr;
+    size_t size = 0;
+    bool owned = true;       /* freed by release */
+    bool lazy = false;       /* created with data == NULL: allocated on first real use */
+    bool image = false;
+    uint32_t w = 0, h = 0, layers = 0;
+    std::vector<uint8_t> shadow;   /* host copy of uploaded data (scene arrays are re-read by scene prep) */
+    bool gen_valid = false;        /* holds rays "generated" by a fused raygen launch */
+    bool gen_materialised = false;
+    RaygenArgs gen{};
+};
+
+struct ArgValue {
+    bool set = false;
+    size_t size = 0;
+    uint8_t bytes[32] = {0};
+};
+
+struct Kernel {
+    KernelKind kind;
+    std::string name;
+    ArgValue values[__MAX_BUFFERS];
+};
+
+struct TimingEntry { hipEvent_t start, stop; cl_uint kernel; };
+
+struct Impl {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<Kernel> kernels;
+    std::vector<Buffer*> live;      /* every buffer handed out as a cl_mem handle */
+    /* knobs */
+    int depth = 15;
+    int strict = 0;
+    int fuse = 1;
+    int async = 0;
+    int variant = 0;
+    int counting = 0;
+    uint64_t id_offset = 0;
+    float* debug_rgb = nullptr;
+    /* prepared scene cache */
+    const Buffer *prep_s = nullptr, *prep_p = nullptr, *prep_l = nullptr;
+    uint32_t prep_ns = 0, prep_np = 0, prep_nl = 0;
+    float* d_geom = nullptr; size_t geom_f4 = 0;
+    float* d_ptex = nullptr;
+    unsigned long long* d_counters = nullptr;
+    /* timing log */
+    std::vector<TimingEntry> timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+};
+
+Impl* impl_of(const cl_wrap* w) {
+    if (!w || !w->impl) die("cl_wrap is not initialised");
+    return (Impl*)w->impl;
+}
+
+void use_device(Impl* I) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != I->device) HIP_OK(hipSetDevice(I->device), "Cannot select the HIP device");
+}
+
+bool is_registered(const cl_wrap* w, cl_uint kernel_id, cl_uint arg_id) {
+    for (cl_uint i = 0; i < w->buffers_num[kernel_id]; i++)
+        if (w->buffers_ids[kernel_id][i] == arg_id) return true;
+    return false;
+}
+
+void check_kernel_id(const cl_wrap* w, cl_uint kernel_id) {
+    if (kernel_id >= w->kernels_num) die("Wrong kernel ID given");
+}
+
+Buffer* new_buffer(Impl* I) {
+    Buffer* b = new Buffer();
+    I->live.push_back(b);
+    return b;
+}
+
+Buffer* lookup_handle(Impl* I, const void* handle) {
+    for (Buffer* b : I->live)
+        if ((const void*)b == handle) return b;
+    return nullptr;
+}
+
+void ensure_allocated(Impl* I, Buffer* b) {
+    (void)I;
+    if (b->dptr || b->size == 0) return;
+    HIP_OK(hipMalloc(&b->dptr, b->size), "Couldn't allocate device memory");
+    b->lazy = false;
+}
+
+void register_buffer(cl_wrap* w, cl_uint kernel_id, cl_uint arg_id, Buffer* b) {
+    w->buffers[kernel_id][arg_id] = (cl_mem)b;
+    w->buffers_ids[kernel_id][w->buffers_num[kernel_id]++] = arg_id;
+}
+
+void precheck_buffer_arg(cl_wrap* w, cl_uint kernel_id, cl_uint arg_id) {
+    check_kernel_id(w, kernel_id);
+    if (arg_id < __MAX_BUFFERS && is_registered(w, kernel_id, arg_id)) die("Given kernel argument already in use");
+    if (arg_id >= __MAX_BUFFERS) die("Wrong kernel ID given"); /* the reference's wording (opencl_wrap.c:144) */
+}
+
+/* ---- launch helpers -------------------------------------------------------------------- */
+std::pair<hipEvent_t, hipEvent_t> take_events(Impl* I) {
+    if (!I->free_events.empty()) {
+        auto p = I->free_events.back();
+        I->free_events.pop_back();
+        return p;
+    }
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a), "Couldn't create a timing event");
+    HIP_OK(hipEventCreate(&b), "Couldn't create a timing event");
+    return {a, b};
+}
+
+struct LaunchTimer {
+    Impl* I; cl_uint kernel; bool on; std::pair<hipEvent_t, hipEvent_t> ev;
+    LaunchTimer(Impl* I_, cl_uint k) : I(I_), kernel(k), on(I_->timing.size() < 16384) {
+        if (on) { ev = take_events(I); HIP_OK(hipEventRecord(ev.first, I->stream), "Couldn't run the kernel"); }
+    }
+    void done() {
+        if (on) { HIP_OK(hipEventRecord(ev.second, I->stream), "Couldn't run the kernel"); I->timing.push_back({ev.first, ev.second, kernel}); }
+    }
+};
+
+void finish(Impl* I) {
+    hipError_t e = hipStreamSynchronize(I->stream);
+    if (e != hipSuccess) { printf("%d\n", (int)e); die("The device kernel failed"); }
+}
+
+const ArgValue& need_value(const Kernel& k, cl_uint arg, size_t min_size, size_t max_size) {
+    const ArgValue& v = k.values[arg];
+    if (!v.set || v.size < min_size || v.size > max_size) die("Couldn't run the kernel");
+    return v;
+}
+
+RaygenArgs snapshot_raygen(Impl* I, const Kernel& k, size_t array_size) {
+    RaygenArgs g{};
+    memcpy(g.corner, need_value(k, 0, 12, 16).bytes, 12);
+    memcpy(g.origin, need_value(k, 1, 12, 16).bytes, 12);
+    memcpy(g.up, need_value(k, 2, 12, 16).bytes, 12);
+    memcpy(g.right, need_value(k, 3, 12, 16).bytes, 12);
+    memcpy(&g.w_factor, need_value(k, 4, 4, 4).bytes, 4);
+    memcpy(&g.h_factor, need_value(k, 5, 4, 4).bytes, 4);
+    memcpy(&g.width, need_value(k, 6, 4, 4).bytes, 4);
+    memcpy(&g.height, need_value(k, 7, 4, 4).bytes, 4);
+    if (g.width == 0 || g.height == 0) die("Couldn't run the kernel");
+    g.id_offset = I->id_offset;
+    /* the reference launches ceil(array_size/local)*local items guarded by id < w*h (raygen.cl:11) */
+    uint64_t rounded = ((uint64_t)array_size + BLOCK - 1) / BLOCK * BLOCK;
+    uint64_t total = (uint64_t)g.width * g.height;
+    uint64_t room = total > g.id_offset ? total - g.id_offset : 0;
+    uint64_t n = rounded < room ? rounded : room;
+    if (n > 0xFFFFFFFFull) die("Couldn't run the kernel");
+    g.n_items = (uint32_t)n;
+    return g;
+}
+
+void run_raygen_kernel(Impl* I, const RaygenArgs& g, Buffer* rays, cl_uint kernel_id) {
+    ensure_allocated(I, rays);
+    size_t cap = rays->size / 64;
+    uint32_t n = g.n_items < cap ? g.n_items : (uint32_t)cap; /* never write past the buffer */
+    if (n == 0) return;
+    raygen_params P{};
+    memcpy(P.corner, g.corner, 12); memcpy(P.origin, g.origin, 12);
+    memcpy(P.up, g.up, 12); memcpy(P.right, g.right, 12);
+    P.w_factor = g.w_factor; P.h_factor = g.h_factor; P.width = g.width; P.height = g.height;
+    P.id_offset = g.id_offset; P.n_items = n; P.rays = (float*)rays->dptr;
+    LaunchTimer t(I, kernel_id);
+    hipError_t e = I->strict ? wt_strict_launch_raygen(&P, I->stream) : wt_fast_launch_raygen(&P, I->stream);
+    if (e != hipSuccess) die("Couldn't run the kernel");
+    t.done();
+}
+
+void materialise_rays(Impl* I, Buffer* b) {
+    if (b->gen_valid && !b->gen_materialised) {
+        run_raygen_kernel(I, b->gen, b, 0);
+        b->gen_materialised = true;
+    }
+}
+
+uint32_t read_count(const Kernel& k, cl_uint arg) {
+    const ArgValue& v = k.values[arg];
+    if (!v.set) die("Couldn't run the kernel");
+    switch (v.size) { /* uchar in the reference (raytracing.cl:17); 2/4 bytes = wide-count extension */
+        case 1: return v.bytes[0];
+        case 2: { uint16_t x; memcpy(&x, v.bytes, 2); return x; }
+        case 4: { uint32_t x; memcpy(&x, v.bytes, 4); return x; }
+        default: die("Couldn't run the kernel");
+    }
+}
+
+const uint8_t* host_view(Impl* I, Buffer* b, size_t need, std::vector<uint8_t>& tmp) {
+    if (b->size < need) die("Couldn't run the kernel");
+    if (b->shadow.size() >= need) return b->shadow.data();
+    ensure_allocated(I, b);
+    tmp.resize(need);
+    if (need) HIP_OK(hipMemcpy(tmp.data(), b->dptr, need, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    return tmp.data();
+}
+
+void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buffer* l, uint32_t nl) {
+    if (I->d_geom && I->prep_s == s && I->prep_p == p && I->prep_l == l && I->prep_ns == ns &&
+        I->prep_np == np && I->prep_nl == nl)
+        return;
+    std::vector<uint8_t> ts, tp, tl;
+    const uint8_t* hs = host_view(I, s, 96 * (size_t)ns, ts);
+    const uint8_t* hp = host_view(I, p, 96 * (size_t)np, tp);
+    const uint8_t* hl = host_view(I, l, 48 * (size_t)nl, tl);
+    size_t f4 = wprep_geom_f4(ns, np, nl);
+    std::vector<float> geom(4 * (f4 ? f4 : 1)), ptex(8 * (size_t)(np ? np : 1));
+    wprep_build(hs, ns, hp, np, hl, nl, geom.data(), ptex.data());
+    if (I->d_geom) { (void)hipFree(I->d_geom); I->d_geom = nullptr; }
+    if (I->d_ptex) { (void)hipFree(I->d_ptex); I->d_ptex = nullptr; }
+    HIP_OK(hipMalloc((void**)&I->d_geom, geom.size() * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMalloc((void**)&I->d_ptex, ptex.size() * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMemcpy(I->d_geom, geom.data(), geom.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    HIP_OK(hipMemcpy(I->d_ptex, ptex.data(), ptex.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    I->geom_f4 = f4;
+    I->prep_s = s; I->prep_p = p; I->prep_l = l; I->prep_ns = ns; I->prep_np = np; I->prep_nl = nl;
+}
+
+Buffer* buffer_arg(cl_wrap* w, cl_uint kernel_id, cl_uint arg) {
+    if (!is_registered(w, kernel_id, arg)) die("Couldn't run the kernel");
+    return (Buffer*)w->buffers[kernel_id][arg];
+}
+
+void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
+    Kernel& k = I->kernels[kid];
+    /* arg 0: the ray buffer, passed by value as the 8 bytes of a handle (raypng.c:61) or bound as a buffer */
+    Buffer* rays = nullptr;
+    if (is_registered(w, kid, 0)) rays = (Buffer*)w->buffers[kid][0];
+    else {
+        const ArgValue& v = need_value(k, 0, sizeof(cl_mem), sizeof(cl_mem));
+        void* h; memcpy(&h, v.bytes, sizeof h);
+        rays = lookup_handle(I, h);
+        if (!rays) die("Couldn't run the kernel");
+    }
+    Buffer* bs = buffer_arg(w, kid, 1);
+    Buffer* bp = buffer_arg(w, kid, 2);
+    Buffer* bl = buffer_arg(w, kid, 3);
+    uint32_t ns = read_count(k, 4), np = read_count(k, 5), nl = read_count(k, 6);
+    uint32_t total; memcpy(&total, need_value(k, 7, 4, 4).bytes, 4);
+    Buffer* tex = buffer_arg(w, kid, 8);
+    Buffer* sky = buffer_arg(w, kid, 9);
+    Buffer* out = buffer_arg(w, kid, 10);
+    if (!tex->image || !sky->image) die("Couldn't run the kernel");
+
+    uint64_t rounded = ((uint64_t)array_size + BLOCK - 1) / BLOCK * BLOCK;
+    uint64_t n64 = rounded < total ? rounded : total;      /* guard `id >= total_size` (raytracing.cl:24) */
+    ensure_allocated(I, out);
+    if (n64 > out->size / 4) n64 = out->size / 4;          /* never write past the framebuffer */
+    if (n64 == 0) return;
+    if (n64 > 0xFFFFFFFFull) die("Couldn't run the kernel");
+
+    prepare_scene(I, bs, ns, bp, np, bl, nl);
+    ensure_allocated(I, bs); ensure_allocated(I, bp);
+
+    whitted_params P{};
+    P.n_items = (uint32_t)n64;
+    P.depth = I->depth;
+    P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
+    P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
+    P.ns = ns; P.np = np; P.nl = nl;
+    P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
+    P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
+    P.out = (uint32_t*)out->dptr;
+    P.out_rgb = I->debug_rgb;
+
+    int flags = 0;
+    const bool fused = I->fuse && rays->gen_valid;
+    if (fused) {
+        const RaygenArgs& g = rays->gen;
+        memcpy(P.corner, g.corner, 12); memcpy(P.origin, g.origin, 12);
+        memcpy(P.up, g.up, 12); memcpy(P.right, g.right, 12);
+        P.w_factor = g.w_factor; P.h_factor = g.h_factor; P.width = g.width; P.height = g.height;
+        P.id_offset = g.id_offset;
+        if (P.n_items > g.n_items) P.n_items = g.n_items; /* rays past the generated range are undefined in the reference */
+        if (P.n_items == 0) return;
+        P.tiled = (g.id_offset % g.width == 0) && (P.n_items % g.width == 0) && !(I->variant & 2);
+        P.rows = P.n_items / g.width;
+    } else {
+        materialise_rays(I, rays);
+        ensure_allocated(I, rays);
+        if ((uint64_t)P.n_items * 64 > rays->size) die("Couldn't run the kernel");
+        P.rays = (const float*)rays->dptr;
+        P.id_offset = I->id_offset;
+        P.width = 1; P.height = 1;
+        flags |= F_RAYS;
+    }
+    if (I->depth > LDS_LEVELS + 1) flags |= F_DEEP;
+    size_t dyn_lds = 0;
+    if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
+    if (I->counting) {
+        flags |= F_COUNT;
+        if (!I->d_counters) {
+            HIP_OK(hipMalloc((void**)&I->d_counters, 8 * sizeof(unsigned long long)), "Couldn't allocate device memory");
+            HIP_OK(hipMemsetAsync(I->d_counters, 0, 8 * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
+        }
+        P.counters = I->d_counters;
+    }
+    unsigned grid;
+    if (P.tiled) {
+        unsigned trows = (P.rows + 7) / 8, tpr = (P.width + 31) / 32;
+        grid = 8 * ((trows + 7) / 8) * tpr;
+    } else {
+        grid = (P.n_items + BLOCK - 1) / BLOCK;
+    }
+    LaunchTimer t(I, kid);
+    hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
+                             : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
+    if (e != hipSuccess) die("Couldn't run the kernel");
+    t.done();
+}
+
+void run_raygen(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
+    Kernel& k = I->kernels[kid];
+    Buffer* rays = buffer_arg(w, kid, 8);
+    RaygenArgs g = snapshot_raygen(I, k, array_size);
+    rays->gen = g;
+    rays->gen_valid = true;
+    rays->gen_materialised = false;
+    if (!I->fuse) {
+        run_raygen_kernel(I, g, rays, kid);
+        rays->gen_materialised = true;
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+} /* namespace */
+
+/* ======================================================================================== */
+extern "C" {
+
+void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
+    memset(wrap, 0, sizeof *wrap);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) die("Cannot find a HIP platform");
+    if (!(type & (CL_DEVICE_TYPE_GPU | CL_DEVICE_TYPE_DEFAULT)) || count <= 0)
+        die("Cannot find a device of the given type");
+
+    Impl* I = new Impl();
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    I->device = env_int("CLWRAP_DEVICE", cur);
+    if (I->device < 0 || I->device >= count) die("Cannot find a device of the given type");
+    HIP_OK(hipSetDevice(I->device), "Could not create a HIP context from device");
+
+    va_list vars;
+    va_start(vars, type);
+    const char* path = va_arg(vars, const char*);
+    while (path) {
+        const char* name = va_arg(vars, const char*);
+        if (!name) { va_end(vars); die("Source file was not followed by kernel name"); }
+        if (I->kernels.size() >= __MAX_KERNELS) { va_end(vars); die("Too many kernels"); }
+        Kernel k;
+        k.name = name;
+        /* kernels are precompiled: identity comes from the NAME, the source path is not read */
+        if (k.name == "raygen") k.kind = K_RAYGEN;
+        else if (k.name == "raytracer") k.kind = K_RAYTRACER;
+        else { va_end(vars); die("Couldn't create the CL kernel from: %s", name); }
+        I->kernels.push_back(k);
+        path = va_arg(vars, const char*);
+    }
+    va_end(vars);
+
+    HIP_OK(hipStreamCreateWithFlags(&I->own_stream, hipStreamNonBlocking), "Couldn't create a command queue for the given device");
+    I->stream = I->own_stream;
+    I->depth = env_int("CLWRAP_DEPTH", 15);
+    if (I->depth < 1 || I->depth > CLW_MAX_DEPTH) die("CLWRAP_DEPTH must be in [1, %d]", CLW_MAX_DEPTH);
+    I->strict = env_int("CLWRAP_STRICT", 0) ? 1 : 0;
+    I->fuse = env_int("CLWRAP_FUSE", 1) ? 1 : 0;
+    I->variant = env_int("CLWRAP_VARIANT", 0);
+
+    wrap->impl = I;
+    wrap->kernels_num = (cl_uint)I->kernels.size();
+}
+
+void cl_wrap_load_global_data(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, const void* data,
+                              size_t size, cl_mem_flags mem_flags) {
+    (void)mem_flags;
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    precheck_buffer_arg(wrap, kernel_id, arg_id);
+    Buffer* b = new_buffer(I);
+    b->size = size;
+    if (data) {
+        ensure_allocated(I, b);
+        if (size) {
+            if (hipMemcpy(b->dptr, data, size, hipMemcpyHostToDevice) != hipSuccess)
+                die("Couldn't transfer the data from host to the device");
+            if (size <= (64u << 20)) b->shadow.assign((const uint8_t*)data, (const uint8_t*)data + size);
+        }
+    } else {
+        b->lazy = true; /* e.g. the 64 B/pixel ray buffer: stays virtual unless somebody needs the bytes */
+    }
+    register_buffer(wrap, kernel_id, arg_id, b);
+}
+
+void cl_wrap_load_single_data(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, const void* data, size_t obj_size) {
+    Impl* I = impl_of(wrap);
+    check_kernel_id(wrap, kernel_id);
+    if (arg_id < __MAX_BUFFERS && is_registered(wrap, kernel_id, arg_id)) die("Given kernel argument already in use");
+    if (arg_id >= __MAX_BUFFERS || !data || obj_size == 0 || obj_size > sizeof(ArgValue::bytes))
+        die("Couldn't pass the data argument to the kernel");
+    ArgValue& v = I->kernels[kernel_id].values[arg_id];
+    memcpy(v.bytes, data, obj_size); /* copied at call time, like clSetKernelArg */
+    v.size = obj_size;
+    v.set = true;
+}
+
+static void install_images(cl_wrap* wrap, Impl* I, cl_uint kernel_id, cl_uint arg_id, const uint8_t* rgba,
+                           uint32_t w, uint32_t h, uint32_t layers) {
+    Buffer* b = new_buffer(I);
+    b->size = (size_t)w * h * layers * 4;
+    b->image = true; b->w = w; b->h = h; b->layers = layers;
+    if (b->size == 0) die("Couldn't create an image array %d", -40);
+    ensure_allocated(I, b);
+    if (hipMemcpy(b->dptr, rgba, b->size, hipMemcpyHostToDevice) != hipSuccess)
+        die("Couldn't create an image array %d", -1);
+    register_buffer(wrap, kernel_id, arg_id, b);
+}
+
+void cl_wrap_load_images(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, cl_mem_flags mem_flags,
+                         cl_uint image_num, ...) {
+    (void)mem_flags;
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    precheck_buffer_arg(wrap, kernel_id, arg_id);
+    std::vector<uint8_t> all;
+    uint32_t W = 0, H = 0;
+    va_list vars;
+    va_start(vars, image_num);
+    for (cl_uint i = 0; i < image_num; i++) {
+        const char* filename = va_arg(vars, const char*);
+        uint32_t w = 0, h = 0;
+        uint8_t* px = nullptr;
+        int rc = wpng_read_rgba(filename, &w, &h, &px);
+        switch (rc) { /* the reference's messages (opencl_wrap.c:233-307) */
+            case WPNG_OK: break;
+            case WPNG_ERR_OPEN: va_end(vars); die("Cannot open file \"%s\"", filename);
+            case WPNG_ERR_NOT_PNG: va_end(vars); die("\"%s\" is not a PNG file", filename);
+            case WPNG_ERR_FORMAT: va_end(vars); die("\"%s\" must have a depth of 8 bits and be RGB", filename);
+            default: va_end(vars); die("Could not decode PNG file \"%s\" (code %d)", filename, rc);
+        }
+        if (i == 0) { W = w; H = h; all.reserve((size_t)w * h * 4 * image_num); }
+        if (w != W || h != H) { free(px); va_end(vars); die("All images must have same dimensions"); }
+        all.insert(all.end(), px, px + (size_t)w * h * 4);
+        free(px);
+    }
+    va_end(vars);
+    install_images(wrap, I, kernel_id, arg_id, all.data(), W, H, image_num);
+}
+
+void cl_wrap_output(cl_wrap* wrap, size_t array_size, size_t output_size, cl_uint kernel_run_id,
+                    cl_uint kernel_id, cl_int arg_id, void* host_output) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    check_kernel_id(wrap, kernel_run_id);
+    if (I->kernels[kernel_run_id].kind == K_RAYGEN) run_raygen(wrap, I, kernel_run_id, array_size);
+    else run_raytracer(wrap, I, kernel_run_id, array_size);
+
+    if (!host_output) {
+        if (!I->async) finish(I);
+        return;
+    }
+    /* blocking device -> host copy of buffers[kernel_id][arg_id] (opencl_wrap.c:390-397) */
+    check_kernel_id(wrap, kernel_id);
+    if (arg_id < 0 || arg_id >= __MAX_BUFFERS || !is_registered(wrap, kernel_id, (cl_uint)arg_id))
+        die("Failed to transfer device memory to host");
+    Buffer* b = (Buffer*)wrap->buffers[kernel_id][arg_id];
+    materialise_rays(I, b);
+    ensure_allocated(I, b);
+    if (output_size > b->size) die("Failed to transfer device memory to host");
+    if (output_size &&
+        hipMemcpyAsync(host_output, b->dptr, output_size, hipMemcpyDeviceToHost, I->stream) != hipSuccess)
+        die("Failed to transfer device memory to host");
+    finish(I);
+}
+
+void cl_wrap_release(cl_wrap* wrap) {
+    if (!wrap || !wrap->impl) return;
+    Impl* I = (Impl*)wrap->impl;
+    use_device(I);
+    (void)hipStreamSynchronize(I->stream);
+    for (Buffer* b : I->live) {
+        if (b->owned && b->dptr) (void)hipFree(b->dptr);
+        delete b;
+    }
+    if (I->d_geom) (void)hipFree(I->d_geom);
+    if (I->d_ptex) (void)hipFree(I->d_ptex);
+    if (I->d_counters) (void)hipFree(I->d_counters);
+    for (auto& t : I->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto& p : I->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (I->own_stream) (void)hipStreamDestroy(I->own_stream);
+    delete I;
+    memset(wrap, 0, sizeof *wrap);
+}
+
+/* ---------------------------------- extensions ------------------------------------------ */
+void clw_ext_set_depth(cl_wrap* wrap, int depth) {
+    if (depth < 1 || depth > CLW_MAX_DEPTH) die("Trace depth must be in [1, %d]", CLW_MAX_DEPTH);
+    impl_of(wrap)->depth = depth;
+}
+int clw_ext_get_depth(const cl_wrap* wrap) { return impl_of(wrap)->depth; }
+void clw_ext_set_strict(cl_wrap* wrap, int strict) { impl_of(wrap)->strict = strict ? 1 : 0; }
+void clw_ext_set_fuse(cl_wrap* wrap, int fuse) { impl_of(wrap)->fuse = fuse ? 1 : 0; }
+void clw_ext_set_id_offset(cl_wrap* wrap, uint64_t first_id) { impl_of(wrap)->id_offset = first_id; }
+void clw_ext_set_async(cl_wrap* wrap, int async) { impl_of(wrap)->async = async ? 1 : 0; }
+void clw_ext_sync(cl_wrap* wrap) { Impl* I = impl_of(wrap); use_device(I); finish(I); }
+void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {
+    Impl* I = impl_of(wrap);
+    I->stream = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
+}
+void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
+void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
+
+void clw_ext_timing_reset(cl_wrap* wrap) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    finish(I);
+    for (auto& t : I->timing) I->free_events.push_back({t.start, t.stop});
+    I->timing.clear();
+}
+
+void clw_ext_timing_get(cl_wrap* wrap, cl_uint kernel_id, uint32_t* launches, double* total_ms) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    finish(I);
+    uint32_t n = 0;
+    double sum = 0.0;
+    for (auto& t : I->timing) {
+        if (t.kernel != kernel_id) continue;
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, t.start, t.stop), "Couldn't read a timing event");
+        sum += ms;
+        n++;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = sum;
+}
+
+void clw_ext_load_images_raw(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, const uint8_t* rgba,
+                             uint32_t width, uint32_t height, uint32_t layers) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    precheck_buffer_arg(wrap, kernel_id, arg_id);
+    if (!rgba) die("Couldn't create an image array %d", -37);
+    install_images(wrap, I, kernel_id, arg_id, rgba, width, height, layers);
+}
+
+void clw_ext_bind_device_buffer(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, void* device_ptr, size_t size) {
+    Impl* I = impl_of(wrap);
+    precheck_buffer_arg(wrap, kernel_id, arg_id);
+    if (!device_ptr) die("Couldn't pass the data argument to the kernel");
+    Buffer* b = new_buffer(I);
+    b->dptr = device_ptr; b->size = size; b->owned = false;
+    register_buffer(wrap, kernel_id, arg_id, b);
+}
+
+void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    check_kernel_id(wrap, kernel_id);
+    if (arg_id >= __MAX_BUFFERS || !is_registered(wrap, kernel_id, arg_id)) die("Wrong kernel ID given");
+    Buffer* b = (Buffer*)wrap->buffers[kernel_id][arg_id];
+    materialise_rays(I, b);
+    ensure_allocated(I, b);
+    return b->dptr;
+}
+
+void clw_ext_enable_counters(cl_wrap* wrap, int enable) { impl_of(wrap)->counting = enable ? 1 : 0; }
+
+void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    finish(I);
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!I->d_counters) return;
+    unsigned long long h[8];
+    HIP_OK(hipMemcpy(h, I->d_counters, sizeof h, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    HIP_OK(hipMemsetAsync(I->d_counters, 0, sizeof h, I->stream), "Couldn't allocate device memory");
+    finish(I);
+    for (int k = 0; k < 8; k++) out[k] = h[k];
+}
+
+int clw_host_write_png(const char* path, const uint32_t* xrgb, uint32_t width, uint32_t height) {
+    return wpng_write_xrgb(path, xrgb, width, height, 1);
+}
+int clw_host_write_png_rgba(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height) {
+    return wpng_write_rgba_as_rgb(path, rgba, width, height, 1);
+}
+int clw_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgba_malloced) {
+    return wpng_read_rgba(path, width, height, rgba_malloced);
+}
+void clw_host_free(void* p) { free(p); }
+
+const char* clw_ext_version(void) { return "opencl_wrap_hip 0.1 gfx950 fast+strict"; }
+
+} /* extern "C" */

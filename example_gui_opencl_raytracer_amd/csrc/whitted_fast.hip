@@ -1,0 +1,14 @@
+/*
+ * whitted_fast.hip -- the trace kernels in FAST arithmetic: FMA contraction on, native
+ * v_rcp_f32 / v_sqrt_f32 (1 ulp).  This is the envelope an OpenCL device build of the
+ * reference is allowed (x/y <= 2.5 ulp, sqrt <= 3 ulp, contraction permitted), and is the
+ * default, benchmarked path.  Build: hipcc --offload-arch=gfx950 -O3 (default contraction).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "whitted_params.h"
+#define WT_STRICT 0
+#define WT_NS wt_fast
+#define WT_LAUNCH_TRACE wt_fast_launch_trace
+#define WT_LAUNCH_RAYGEN wt_fast_launch_raygen
+#include "whitted_launch.inc"

@@ -1,0 +1,59 @@
+/*
+ * whitted_params.h -- launch parameters shared by the host shim and the HIP kernels.
+ *
+ * "Prepared geometry": one float4 stream per scene, built once on the host from the raw
+ * wire structs (scene_prep.c) so the intersection loops read 16 B per sphere instead of
+ * the 96-B rsphere the reference copies per test (reference primitives.cl:295,338,409):
+ *
+ *   geom[0 .. ns)                 sphere i : { cx, cy, cz, +-r*r }   sign bit set = transparent
+ *   geom[ns + 2p], geom[ns+2p+1]  plane p  : { nx, ny, nz, has_texture ? 1 : 0 }, { px, py, pz, 0 }
+ *   geom[ns + 2np + 2l], [..+1]   light l  : { ox, oy, oz, r*r }, { lr, lg, lb, radius }
+ *                                            with l* = (rgb * intensity) * (1/pi)
+ *   ptex[2p], ptex[2p+1]          plane p  : { b0x, b0y, b0z, texture_scale }, { b1x, b1y, b1z, bits(texture_id) }
+ *                                            (tangent basis of reference primitives.cl:226-236)
+ * Materials stay in the raw arrays and are gathered for the winning primitive only.
+ */
+#ifndef WHITTED_PARAMS_H
+#define WHITTED_PARAMS_H
+#include <stdint.h>
+
+#define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
+
+typedef struct {
+    /* camera: the eight by-value raygen arguments (reference raygen.cl:5-8) */
+    float corner[3], origin[3], up[3], right[3];
+    float w_factor, h_factor;
+    uint32_t width, height;
+    /* work range: work-item i <-> global id id_offset + i, i in [0, n_items) */
+    uint64_t id_offset;
+    uint32_t n_items;
+    uint32_t tiled;        /* 1: range is whole rows -> 8x8 pixel tile per wavefront */
+    uint32_t rows;         /* tiled: number of rows in the range                      */
+    int32_t depth;         /* reference MAX_DEPTH                                     */
+    /* scene */
+    const float* geom;     /* float4 stream, layout above                             */
+    const float* ptex;     /* float4 x 2 per plane                                    */
+    const uint8_t* spheres_raw; /* 96-B rsphere array (materials)                     */
+    const uint8_t* planes_raw;  /* 96-B rplane array                                  */
+    uint32_t ns, np, nl;
+    uint32_t geom_f4;      /* number of float4 in geom                                */
+    /* images: RGBA8 layer stacks */
+    const uint32_t* tex; int32_t tex_w, tex_h, tex_layers;
+    const uint32_t* sky; int32_t sky_w, sky_h;
+    /* I/O */
+    const float* rays;     /* unfused path: 64-B rray records, else NULL              */
+    uint32_t* out;         /* packed 0x00RRGGBB per work-item                         */
+    float* out_rgb;        /* optional float radiance, 3 per work-item                */
+    unsigned long long* counters; /* counting build only: 8 words                     */
+} whitted_params;
+
+typedef struct {
+    float corner[3], origin[3], up[3], right[3];
+    float w_factor, h_factor;
+    uint32_t width, height;
+    uint64_t id_offset;
+    uint32_t n_items;
+    float* rays;           /* 16 floats per work-item                                 */
+} raygen_params;
+
+#endif

@@ -1,0 +1,113 @@
+/*
+ * hip_wrap_ext.h -- entry points the reference API has no slot for.
+ *
+ * The reference bakes these into compile-time macros or has no notion of them:
+ *   depth           #define MAX_DEPTH 15            (reference raytracing.cl:9)
+ *   frame size      #define WIDTH/HEIGHT 800/600    (raypng.c:8-9, rayinteractive.c:13-14)
+ *   counts          one byte each                   (raytracing.cl:17, cpu_obj.c:62-68)
+ *   device / queue  platform 0, device 0, one queue (opencl_wrap.c:26-34, 118-119)
+ * They are needed by the bench driver, the row-strip multi-GPU mode and the parity
+ * tests.  Everything here is optional: a caller that only uses opencl_wrap.h gets the
+ * reference's behaviour.  Plain C ABI: pointers and sizes only.
+ *
+ * Environment variables read once by cl_wrap_init (same meaning as the setters):
+ *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>
+ */
+#ifndef HIP_WRAP_EXT_H
+#define HIP_WRAP_EXT_H
+#include "opencl_wrap.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLW_MAX_DEPTH 32
+
+/* Trace depth (reference MAX_DEPTH).  Default 15.  Errors (print + exit(1)) outside [1, 32]. */
+void clw_ext_set_depth(cl_wrap* wrap, int depth);
+int  clw_ext_get_depth(const cl_wrap* wrap);
+
+/* Arithmetic mode of the trace kernel: 0 = fast (FMA contraction, native rcp/rsq/sqrt --
+ * the envelope an OpenCL device build of the reference is allowed), 1 = strict (no
+ * contraction, IEEE divide/sqrt: tracks the un-contracted oracle). Default 0. */
+void clw_ext_set_strict(cl_wrap* wrap, int strict);
+
+/* 1 (default): a "raygen" launch latches its eight by-value arguments and the trace
+ * kernel synthesises primary rays in registers; the 64 B/pixel ray buffer is only
+ * materialised if somebody reads it back.  0: run the two kernels as the reference does. */
+void clw_ext_set_fuse(cl_wrap* wrap, int fuse);
+
+/* Row strips / sub-ranges: work-item i of the next launches has global id first_id + i
+ * (used for id %% width, id / width and the RNG seed; reference raygen.cl:13-14,
+ * raytracing.cl:33).  Buffers are indexed by i.  Default 0. */
+void clw_ext_set_id_offset(cl_wrap* wrap, uint64_t first_id);
+
+/* 1: cl_wrap_output returns without waiting for the kernel (no host read-back may be
+ * requested in that mode); clw_ext_sync waits.  Default 0 = the reference's behaviour. */
+void clw_ext_set_async(cl_wrap* wrap, int async);
+void clw_ext_sync(cl_wrap* wrap);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * wrapper's own stream.  NULL restores the wrapper's stream. */
+void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream);
+
+/* Per-kernel device timing from hipEvents recorded around every launch on the launch
+ * stream.  reset clears the log; get waits for the logged launches and returns how many
+ * there were and their summed duration in milliseconds. */
+void clw_ext_timing_reset(cl_wrap* wrap);
+void clw_ext_timing_get(cl_wrap* wrap, cl_uint kernel_id, uint32_t* launches, double* total_ms);
+
+/* Texture / skybox layer stack from memory instead of PNG files: `rgba` is
+ * layers*h*w*4 bytes, layer-major, row-major (the image cl_wrap_load_images builds,
+ * opencl_wrap.c:212-332). */
+void clw_ext_load_images_raw(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, const uint8_t* rgba,
+                             uint32_t width, uint32_t height, uint32_t layers);
+
+/* Register caller-owned device memory as buffer argument `arg_id` (not freed by release). */
+void clw_ext_bind_device_buffer(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, void* device_ptr,
+                                size_t size);
+/* Device address of a buffer argument (allocates a lazily created buffer). */
+void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id);
+
+/* Optional float radiance output of the trace kernel: 3 floats per work-item, written
+ * before the 8-bit pack (reference raytracing.cl:193).  NULL disables. */
+void clw_ext_set_debug_rgb(cl_wrap* wrap, void* device_ptr_f32x3);
+
+/* Work counters of the trace kernel.  enable=1 selects the counting build of the kernel
+ * for subsequent launches (slower); read returns and clears
+ *   out[0] path segments  out[1] shadow rays  out[2] light probes  out[3] skybox fetches
+ *   out[4] texel fetches  out[5] refraction pushes  out[6] lane-iterations  out[7] wave-iterations*64
+ * (rays = out[0] + out[1]; out[6]/out[7] = SIMD lane utilisation). */
+void clw_ext_enable_counters(cl_wrap* wrap, int enable);
+void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
+
+/* Kernel build variant for A/B measurements; 0 = default. */
+void clw_ext_set_variant(cl_wrap* wrap, int variant);
+
+/* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
+ * mixed float/double arithmetic (rinit_camera + rgen_perspective, src/cpu_ray.c:8-35, 42-106).
+ * `look` need not be normalised.  Returns 0 for the cameras the reference rejects
+ * (fov ~ 180, fov <= eps, look == +Y; cpu_ray.c:58-63), else 1. */
+typedef struct clw_camera {
+    float im_corner[3], origin[3], up[3], right[3];
+    float w_factor, h_factor;
+    uint32_t width, height;
+} clw_camera;
+int clw_host_perspective(const float origin[3], const float look[3], float fov, float focal,
+                         uint32_t width, uint32_t height, clw_camera* out);
+
+/* Host helpers: PNG files without libpng (reference png_dump, src/cpu_ray.c:108-165, and the
+ * decode step of cl_wrap_load_images).  Return 0 on success. */
+int clw_host_write_png(const char* path, const uint32_t* xrgb, uint32_t width, uint32_t height);
+int clw_host_write_png_rgba(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
+int clw_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgba_malloced);
+void clw_host_free(void* p);
+
+/* Library build info, e.g. "opencl_wrap_hip gfx950 fast+strict". */
+const char* clw_ext_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_WRAP_EXT_H */
