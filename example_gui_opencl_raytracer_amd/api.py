@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libopencl_wrap_hip.so")
+LIB_PATH = os.environ.get("CLWRAP_LIB") or os.path.join(HERE, "libopencl_wrap_hip.so")   # CLWRAP_LIB: A/B builds
 
 MAX_KERNELS = 16  # __MAX_KERNELS, opencl_wrap.h:6
 MAX_BUFFERS = 32  # __MAX_BUFFERS, opencl_wrap.h:7
@@ -31,7 +31,7 @@ SYMBOLS = [
     "cl_wrap_init", "cl_wrap_load_global_data", "cl_wrap_load_single_data", "cl_wrap_load_images",
     "cl_wrap_output", "cl_wrap_release",
     "clw_ext_set_depth", "clw_ext_get_depth", "clw_ext_set_strict", "clw_ext_set_fuse",
-    "clw_ext_set_id_offset", "clw_ext_set_async", "clw_ext_sync", "clw_ext_set_stream",
+    "clw_ext_set_id_offset", "clw_ext_set_row_bands", "clw_ext_set_async", "clw_ext_sync", "clw_ext_set_stream",
     "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
     "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_variant",
@@ -82,6 +82,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                  "clw_ext_set_variant"):
         getattr(L, name).argtypes = [W, C.c_int]
     L.clw_ext_set_id_offset.argtypes = [W, C.c_uint64]
+    L.clw_ext_set_row_bands.argtypes = [W, u32, u32]
     L.clw_ext_sync.argtypes = [W]
     L.clw_ext_set_stream.argtypes = [W, vp]
     L.clw_ext_timing_reset.argtypes = [W]
@@ -210,6 +211,7 @@ class ClWrap:
     def set_strict(self, s): self.L.clw_ext_set_strict(C.byref(self.w), int(s))
     def set_fuse(self, f): self.L.clw_ext_set_fuse(C.byref(self.w), int(f))
     def set_id_offset(self, first_id): self.L.clw_ext_set_id_offset(C.byref(self.w), first_id)
+    def set_row_bands(self, stride, phase): self.L.clw_ext_set_row_bands(C.byref(self.w), stride, phase)
     def set_async(self, a): self.L.clw_ext_set_async(C.byref(self.w), int(a))
     def sync(self): self.L.clw_ext_sync(C.byref(self.w))
     def set_stream(self, s): self.L.clw_ext_set_stream(C.byref(self.w), C.c_void_p(s))

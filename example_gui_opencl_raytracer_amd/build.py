@@ -23,8 +23,10 @@ CC = os.environ.get("CC") or "gcc"
 DEVICE_DEPS = ["whitted_trace.inc", "whitted_launch.inc", "whitted_params.h"]
 UNITS = [
     # (source, compiler, flags, extra deps)
-    ("whitted_fast.hip", "hip", ["-O3", f"--offload-arch={ARCH}"], DEVICE_DEPS),
-    ("whitted_strict.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-ffp-contract=off"], DEVICE_DEPS),
+    # -fno-slp-vectorize: v_pk_{mul,add,fma}_f32 buy no fp32 throughput on gfx950 (plain v_fma_f32 already
+    # runs at the vector peak) but cost aligned register pairs: 126 -> 96 VGPRs and -15 % kernel time here.
+    ("whitted_fast.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-fno-slp-vectorize"], DEVICE_DEPS),
+    ("whitted_strict.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-ffp-contract=off"], DEVICE_DEPS),
     ("hip_wrap.cpp", "hip", ["-O2", "-std=c++17", "-Wall"],
      ["whitted_params.h", "scene_prep.h", "png_codec.h", "../../include/opencl_wrap.h", "../../include/hip_wrap_ext.h"]),
     ("scene_prep.c", "c", ["-O2", "-std=c99", "-ffp-contract=off", "-Wall", "-Wextra"], ["scene_prep.h"]),
@@ -41,12 +43,16 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", extra_device_flags=()) -> str:
+    """tag / extra_device_flags: side-by-side A/B builds (libopencl_wrap_hip<tag>.so, see tools/)."""
     os.makedirs(OBJ, exist_ok=True)
     objs = []
+    lib = LIB if not tag else LIB.replace(".so", f"{tag}.so")
     for src, kind, flags, deps in UNITS:
         spath = os.path.join(CSRC, src)
-        opath = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        opath = os.path.join(OBJ, src.rsplit(".", 1)[0] + tag + ".o")
+        if src.endswith(".hip"):
+            flags = flags + list(extra_device_flags)
         objs.append(opath)
         dpaths = [spath, __file__] + [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
         if not force and not _newer(opath, dpaths):
@@ -55,12 +61,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    if force or _newer(LIB, objs):
-        cmd = [HIPCC, "-shared", "-o", LIB] + objs + ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
+    if force or _newer(lib, objs):
+        cmd = [HIPCC, "-shared", "-o", lib] + objs + ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -63,6 +63,7 @@ struct RaygenArgs { /* snapshot of the eight by-value raygen arguments + the lau
     uint32_t width, height;
     uint64_t id_offset;
     uint32_t n_items;
+    uint32_t band_stride, band_phase;
 };
 
 struct Buffer {
@@ -106,6 +107,7 @@ struct Impl {
     int variant = 0;
     int counting = 0;
     uint64_t id_offset = 0;
+    uint32_t band_stride = 1, band_phase = 0;
     float* debug_rgb = nullptr;
     /* prepared scene cache */
     const Buffer *prep_s = nullptr, *prep_p = nullptr, *prep_l = nullptr;
@@ -214,10 +216,15 @@ RaygenArgs snapshot_raygen(Impl* I, const Kernel& k, size_t array_size) {
     memcpy(&g.height, need_value(k, 7, 4, 4).bytes, 4);
     if (g.width == 0 || g.height == 0) die("Couldn't run the kernel");
     g.id_offset = I->id_offset;
+    g.band_stride = I->band_stride; g.band_phase = I->band_phase;
     /* the reference launches ceil(array_size/local)*local items guarded by id < w*h (raygen.cl:11) */
     uint64_t rounded = ((uint64_t)array_size + BLOCK - 1) / BLOCK * BLOCK;
     uint64_t total = (uint64_t)g.width * g.height;
     uint64_t room = total > g.id_offset ? total - g.id_offset : 0;
+    if (g.band_stride > 1) {   /* this launch owns every band_stride-th 8-row band of the frame */
+        if (g.id_offset != 0 || g.height % (8 * g.band_stride) != 0) die("Row bands need height %% (8*stride) == 0 and no id offset");
+        room = total / g.band_stride;
+    }
     uint64_t n = rounded < room ? rounded : room;
     if (n > 0xFFFFFFFFull) die("Couldn't run the kernel");
     g.n_items = (uint32_t)n;
@@ -234,6 +241,7 @@ void run_raygen_kernel(Impl* I, const RaygenArgs& g, Buffer* rays, cl_uint kerne
     memcpy(P.up, g.up, 12); memcpy(P.right, g.right, 12);
     P.w_factor = g.w_factor; P.h_factor = g.h_factor; P.width = g.width; P.height = g.height;
     P.id_offset = g.id_offset; P.n_items = n; P.rays = (float*)rays->dptr;
+    P.band_stride = g.band_stride; P.band_phase = g.band_phase;
     LaunchTimer t(I, kernel_id);
     hipError_t e = I->strict ? wt_strict_launch_raygen(&P, I->stream) : wt_fast_launch_raygen(&P, I->stream);
     if (e != hipSuccess) die("Couldn't run the kernel");
@@ -343,9 +351,10 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
         memcpy(P.up, g.up, 12); memcpy(P.right, g.right, 12);
         P.w_factor = g.w_factor; P.h_factor = g.h_factor; P.width = g.width; P.height = g.height;
         P.id_offset = g.id_offset;
+        P.band_stride = g.band_stride; P.band_phase = g.band_phase;
         if (P.n_items > g.n_items) P.n_items = g.n_items; /* rays past the generated range are undefined in the reference */
         if (P.n_items == 0) return;
-        P.tiled = (g.id_offset % g.width == 0) && (P.n_items % g.width == 0) && !(I->variant & 2);
+        P.tiled = (g.id_offset % g.width == 0 || g.band_stride > 1) && (P.n_items % g.width == 0) && !(I->variant & 2);
         P.rows = P.n_items / g.width;
     } else {
         materialise_rays(I, rays);
@@ -354,6 +363,10 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
         P.rays = (const float*)rays->dptr;
         P.id_offset = I->id_offset;
         P.width = 1; P.height = 1;
+        if (rays->gen_valid) {   /* ids (RNG seeds) follow the launch that generated the rays */
+            P.id_offset = rays->gen.id_offset; P.width = rays->gen.width; P.height = rays->gen.height;
+            P.band_stride = rays->gen.band_stride; P.band_phase = rays->gen.band_phase;
+        } else if (I->band_stride > 1) die("Row bands need a raygen launch");
         flags |= F_RAYS;
     }
     if (I->depth > LDS_LEVELS + 1) flags |= F_DEEP;
@@ -578,6 +591,11 @@ int clw_ext_get_depth(const cl_wrap* wrap) { return impl_of(wrap)->depth; }
 void clw_ext_set_strict(cl_wrap* wrap, int strict) { impl_of(wrap)->strict = strict ? 1 : 0; }
 void clw_ext_set_fuse(cl_wrap* wrap, int fuse) { impl_of(wrap)->fuse = fuse ? 1 : 0; }
 void clw_ext_set_id_offset(cl_wrap* wrap, uint64_t first_id) { impl_of(wrap)->id_offset = first_id; }
+void clw_ext_set_row_bands(cl_wrap* wrap, uint32_t stride, uint32_t phase) {
+    if (stride == 0 || phase >= stride) die("Row bands need 0 <= phase < stride");
+    Impl* I = impl_of(wrap);
+    I->band_stride = stride; I->band_phase = phase;
+}
 void clw_ext_set_async(cl_wrap* wrap, int async) { impl_of(wrap)->async = async ? 1 : 0; }
 void clw_ext_sync(cl_wrap* wrap) { Impl* I = impl_of(wrap); use_device(I); finish(I); }
 void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {

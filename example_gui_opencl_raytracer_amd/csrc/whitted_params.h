@@ -29,6 +29,9 @@ typedef struct {
     uint32_t n_items;
     uint32_t tiled;        /* 1: range is whole rows -> 8x8 pixel tile per wavefront */
     uint32_t rows;         /* tiled: number of rows in the range                      */
+    /* interleaved 8-row bands (multi-GPU load balance): local row y is global row
+     * ((y/8)*band_stride + band_phase)*8 + y%8; band_stride <= 1 = contiguous range        */
+    uint32_t band_stride, band_phase;
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */
     const float* geom;     /* float4 stream, layout above                             */
@@ -53,6 +56,7 @@ typedef struct {
     uint32_t width, height;
     uint64_t id_offset;
     uint32_t n_items;
+    uint32_t band_stride, band_phase;
     float* rays;           /* 16 floats per work-item                                 */
 } raygen_params;
 

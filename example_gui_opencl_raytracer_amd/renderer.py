@@ -34,11 +34,14 @@ def strip_rows(height: int, world: int, rank: int) -> tuple[int, int]:
 class Renderer:
     def __init__(self, scene: Scene, tex: np.ndarray, sky: np.ndarray, width: int, height: int, *,
                  depth: int = 15, strict: bool = False, fuse: bool = True, first_row: int = 0,
-                 rows: int | None = None, framebuffer_ptr: int | None = None, wide_counts: bool | None = None,
+                 rows: int | None = None, bands: tuple[int, int] | None = None, framebuffer_ptr: int | None = None, wide_counts: bool | None = None,
                  texture_paths=None, skybox_path=None):
         self.width, self.height = width, height
         self.first_row = first_row
         self.rows = height - first_row if rows is None else rows
+        if bands is not None:                              # (stride, phase): every stride-th 8-row band
+            assert first_row == 0 and rows is None and height % (8 * bands[0]) == 0
+            self.rows = height // bands[0]
         self.pixels = self.rows * width                   # work-items of this renderer
         self.scene = scene
         w = self.w = api.ClWrap("src/cl/raygen.cl", "raygen", "src/cl/raytracing.cl", "raytracer")
@@ -46,6 +49,8 @@ class Renderer:
         w.set_strict(strict)
         w.set_fuse(fuse)
         w.set_id_offset(first_row * width)
+        if bands is not None:
+            w.set_row_bands(*bands)
 
         u32 = lambda v: np.uint32(v)
         w.load_single_data(0, 6, u32(width))

@@ -68,13 +68,30 @@ def glass():
     return _material((0, 0, 0), 0.1, 0.0, 0.0, 20, True, True, 1.52, 0.04, 0, 0.0)
 
 
+def _copy_fields(dst, src):
+    for name in dst.dtype.names:
+        if dst.dtype[name].names:
+            _copy_fields(dst[name], src[name])
+        else:
+            dst[name] = src[name]
+
+
+def _canonical(a, dt):
+    """Copy `a` into a fresh record array of dtype `dt` whose struct padding is zero (numpy
+    leaves padding bytes undefined when it copies structured arrays)."""
+    a = np.asarray(a, dtype=dt).reshape(-1)
+    out = np.zeros(len(a), dt)
+    _copy_fields(out, a)
+    return out
+
+
 class Scene:
-    """Spheres / planes / lights as numpy record arrays in wire layout."""
+    """Spheres / planes / lights as numpy record arrays in wire layout (padding bytes zero)."""
 
     def __init__(self, spheres, planes, lights):
-        self.spheres = np.ascontiguousarray(spheres, dtype=SPHERE).reshape(-1)
-        self.planes = np.ascontiguousarray(planes, dtype=PLANE).reshape(-1)
-        self.lights = np.ascontiguousarray(lights, dtype=LIGHT).reshape(-1)
+        self.spheres = _canonical(spheres, SPHERE)
+        self.planes = _canonical(planes, PLANE)
+        self.lights = _canonical(lights, LIGHT)
 
     @property
     def counts(self):

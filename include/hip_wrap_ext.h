@@ -43,6 +43,12 @@ void clw_ext_set_fuse(cl_wrap* wrap, int fuse);
  * raytracing.cl:33).  Buffers are indexed by i.  Default 0. */
 void clw_ext_set_id_offset(cl_wrap* wrap, uint64_t first_id);
 
+/* Interleaved row bands (balanced multi-GPU sharding): with stride S > 1 the next launches own
+ * every S-th 8-row band of the frame, starting at band `phase`: local row y is global row
+ * ((y / 8) * S + phase) * 8 + y % 8.  Needs height % (8 * S) == 0 and id offset 0.
+ * stride 1 (default) = one contiguous range. */
+void clw_ext_set_row_bands(cl_wrap* wrap, uint32_t stride, uint32_t phase);
+
 /* 1: cl_wrap_output returns without waiting for the kernel (no host read-back may be
  * requested in that mode); clw_ext_sync waits.  Default 0 = the reference's behaviour. */
 void clw_ext_set_async(cl_wrap* wrap, int async);

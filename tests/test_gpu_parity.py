@@ -1,0 +1,204 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (cl_wrap_*), against the oracle.
+
+Bars (written here as the tolerances):
+  strict build  (no contraction, IEEE divide/sqrt)   >= 99.9 % of pixels bit-exact, ray counts equal
+  fast build    (FMA contraction, native rcp/sqrt)   >= 99.5 % bit-exact, >= 99.8 % within 1 LSB per
+                                                     channel, float radiance within 1e-4 on >= 99.5 %
+  integer / index work (raygen records are fp but must be bit-exact; ids, packing) bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import CAM, channel_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    import torch  # noqa: F401  (the shim then shares torch's ROCm runtime)
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    return Renderer
+
+
+def gpu_frame(R, sc, tex, sky, w, h, depth, strict, cam=CAM, rgb=False, **kw):
+    r = R(sc, tex, sky, w, h, depth=depth, strict=strict, **kw)
+    r.look(**cam)
+    out = r.render_rgb() if rgb else r.render()
+    r.release()
+    return out
+
+
+def check(got, want, exact_min, le1_min=None):
+    d = channel_diff(got, want)
+    exact, le1 = (d == 0).mean(), (d <= 1).mean()
+    assert exact >= exact_min, f"only {exact:.5f} of pixels bit-exact (need {exact_min})"
+    if le1_min is not None:
+        assert le1 >= le1_min, f"only {le1:.5f} within 1 LSB (need {le1_min})"
+    return exact
+
+
+# ------------------------------------------------------------ golden frames (reference kernels' own output)
+@pytest.mark.parametrize("w,h,depth", [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)])
+def test_strict_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w, h, depth):
+    got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=True)
+    check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.999)
+
+
+@pytest.mark.parametrize("w,h,depth", [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)])
+def test_fast_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w, h, depth):
+    got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=False)
+    check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.995, 0.998)
+
+
+def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
+    """north_star's "1e-4 per-channel float tolerance", on the optional float output."""
+    w, h, depth = 320, 240, 4
+    _, rgb = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=False, rgb=True)
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    _, want, _ = oracle.render(cam, demo_scene, tex, sky, depth, want_rgb=True)
+    err = np.abs(rgb - want).max(1)
+    assert (err <= 1e-4).mean() >= 0.995
+    _, rgb_s = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=True, rgb=True)
+    assert (np.abs(rgb_s - want).max(1) <= 1e-4).mean() >= 0.999
+
+
+# ------------------------------------------------------------ other scenes / cameras vs the oracle
+@pytest.mark.parametrize("origin,look,fov", [((0.8, 2.5, -8.0), (0.0, 0.0, 1.0), 90.0),
+                                             ((-3.0, 0.6, 0.5), (1.0, 0.05, 0.3), 70.0),
+                                             ((0.8, 0.8, 1.5), (0.3, -0.2, 1.0), 100.0),     # inside a glass sphere
+                                             ((1.0, 9.0, 1.0), (0.01, -1.0, 0.02), 60.0)])
+def test_cameras(R, oracle, demo_scene, tex, sky, origin, look, fov):
+    w, h, depth = 128, 96, 15
+    cam = dict(origin=origin, look=look, fov=fov, focal=1.0)
+    want, _, _ = oracle.render(oracle.camera(origin, look, fov, 1.0, w, h), demo_scene, tex, sky, depth)
+    check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4, 5, 8, 15, 32])
+def test_depths_including_the_scratch_stack(R, oracle, demo_scene, tex, sky, depth):
+    """depth <= 4 keeps the DFS stack in LDS; deeper levels spill to scratch (other kernel build)."""
+    w, h = 160, 120
+    want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, depth)
+    check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True), want, 0.999)
+    if depth >= 8:
+        assert cnt.max_stack > 4          # the deep levels really are exercised
+
+
+def test_glass_field_divergence_scene(R, oracle, tex, sky):
+    """Config C3's scene at a size the oracle renders in seconds: 64 dielectric spheres, depth 8."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.dielectric_field_scene(8)
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    w, h, depth = 256, 256, 8
+    want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
+    assert cnt.pushes > 10000 and cnt.tir_drops > 0
+    check(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.98, 0.99)
+
+
+def test_many_spheres_wide_counts_and_global_geometry_path(R, oracle, tex, sky):
+    """Config C4's scene shrunk (40x40 = 1600 spheres > 255 -> 4-byte counts; > 1024 float4 of
+    geometry -> read from global memory instead of LDS)."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.sphere_grid_scene(40, 40)
+    cam = dict(origin=(0.0, 6.0, -6.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
+    w, h, depth = 96, 54, 2
+    want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
+    check(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
+
+
+def test_lds_and_global_geometry_paths_agree_exactly(R, demo_scene, tex, sky):
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    outs = []
+    for variant in (0, 1, 2, 3):               # bit 0: geometry from global memory, bit 1: linear id mapping
+        r = Renderer(demo_scene, tex, sky, 160, 120, depth=15, strict=True)
+        r.w.set_variant(variant)
+        r.look(**CAM)
+        outs.append(r.render())
+        r.release()
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+# ------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (33, 9), (150, 101), (257, 8)])
+def test_ragged_sizes(R, oracle, demo_scene, tex, sky, w, h):
+    want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, 4)
+    got = gpu_frame(R, demo_scene, tex, sky, w, h, 4, True)
+    assert got.shape == want.shape
+    check(got, want, 0.995 if w * h > 1000 else 0.95)
+
+
+def test_empty_primitive_lists(R, oracle, demo_scene, tex, sky):
+    from example_gui_opencl_raytracer_amd.scene import Scene
+    w, h = 96, 64
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    cases = {
+        "no spheres": Scene(demo_scene.spheres[:0], demo_scene.planes, demo_scene.lights),
+        "no planes": Scene(demo_scene.spheres, demo_scene.planes[:0], demo_scene.lights),
+        "no lights": Scene(demo_scene.spheres, demo_scene.planes, demo_scene.lights[:0]),
+        "sky only": Scene(demo_scene.spheres[:0], demo_scene.planes[:0], demo_scene.lights[:0]),
+    }
+    for name, sc in cases.items():
+        want, _, _ = oracle.render(cam, sc, tex, sky, 4)
+        got = gpu_frame(R, sc, tex, sky, w, h, 4, True)
+        assert (channel_diff(got, want) == 0).mean() >= 0.999, name
+
+
+def test_count_width_is_irrelevant(R, demo_scene, tex, sky):
+    a = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=False)     # uchar counts (reference)
+    b = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=True)      # 4-byte counts (extension)
+    assert np.array_equal(a, b)
+
+
+def test_pixel_zero_has_the_stuck_rng(R, oracle, demo_scene, tex, sky):
+    """id 0 seeds xorshift with 0, its fixed point (raytracing.cl:33): both sides must agree there."""
+    w, h = 64, 48
+    want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, 4)
+    got = gpu_frame(R, demo_scene, tex, sky, w, h, 4, True)
+    assert got[0] == want[0]
+
+
+# ------------------------------------------------------------ BASELINE.json sizes: properties + counters
+def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, tex):
+    """Config C2 (1920x1080, depth 4, 4096x3072 skybox) -- the bench workload itself."""
+    from example_gui_opencl_raytracer_amd import textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sky4k = textures.skybox_cross(4096)
+    w, h, depth = 1920, 1080, 4
+    want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky4k, depth)
+    assert 13.8 < cnt.rays / (w * h) < 13.95                      # 13.88 rays/px
+    for strict, bar in ((True, 0.9995), (False, 0.995)):
+        r = Renderer(demo_scene, tex, sky4k, w, h, depth=depth, strict=strict)
+        r.look(**CAM)
+        got = r.render()
+        check(got, want, bar, None if strict else 0.998)
+        r.w.enable_counters(1)
+        r.render(readback=False)
+        c = r.w.read_counters()
+        r.release()
+        rays = c["segments"] + c["shadow_rays"]
+        assert abs(rays - cnt.rays) <= (0 if strict else 2e-4 * cnt.rays)
+        if strict:
+            assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"], c["texel_fetches"]) == \
+                   (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches, cnt.texel_fetches)
+
+
+def test_large_frame_is_deterministic_and_tile_order_free(R, tex, sky):
+    """4096x4096 (config C3's frame size): two renders are identical, and equal the linear-mapping build."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sc = scene.dielectric_field_scene(8)
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    outs = []
+    for variant in (0, 0, 2):
+        r = Renderer(sc, tex, sky, 4096, 4096, depth=8, strict=False)
+        r.w.set_variant(variant)
+        r.look(**cam)
+        outs.append(r.render())
+        r.release()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert len(np.unique(outs[0])) > 1000

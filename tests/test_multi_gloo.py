@@ -1,0 +1,61 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo groups.  Each rank renders ITS row strip
+(the oracle stands in for the GPU renderer -- tests may use it), the strips are gathered by the
+same `distributed.gather_strips` bench.py uses, and rank 0 compares with a single-rank frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import CAM, ROOT
+
+W, H, DEPTH = 96, 60, 4      # 60 rows: strips of unequal height (8-row tiles: 32/28 and 24/24/12)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from example_gui_opencl_raytracer_amd import distributed as D, scene, textures
+    from example_gui_opencl_raytracer_amd.renderer import strip_rows
+    from oracle.oracle_py import Oracle
+    r, w, _ = D.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    o = Oracle()
+    sc, tex, sky = scene.render_map_scene(), textures.texture_layers(), textures.skybox_cross(512)
+    cam = o.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H)
+    r0, rows = strip_rows(H, world, rank)
+    strip, _, _ = o.render(cam, sc, tex, sky, DEPTH, id_begin=r0 * W, id_end=(r0 + rows) * W, threads=1)
+    full = D.gather_strips(torch.from_numpy(strip.view(np.int32)), W, H, rank, world)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, full.numpy().view(np.uint32))
+    else:
+        assert full is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strips_gather_to_the_single_rank_frame(oracle, demo_scene, tex, sky, tmp_path, world):
+    out = str(tmp_path / f"full_{world}.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H)
+    want, _, _ = oracle.render(cam, demo_scene, tex, sky, DEPTH)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_single_rank_gather_is_identity():
+    from example_gui_opencl_raytracer_amd import distributed as D
+    t = torch.arange(12, dtype=torch.int32)
+    assert D.gather_strips(t, 4, 3, 0, 1) is t

@@ -1,0 +1,155 @@
+"""The CPU restatement (oracle/whitted_oracle.c) against the committed golden fixtures.
+
+The fixtures are outputs of the reference's own kernels compiled for the host
+(oracle/gen_golden.py); the bar is BIT-EXACT: the restatement evaluates the same fp32
+expressions in the same order with the same libm, no contraction."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import CAM
+
+FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)]
+
+
+@pytest.mark.parametrize("w,h,depth", FRAMES)
+def test_frames_bit_exact(oracle, demo_scene, tex, sky, golden_frames, w, h, depth):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    got, _, cnt = oracle.render(cam, demo_scene, tex, sky, depth)
+    want = golden_frames[f"render_map_{w}x{h}_d{depth}"]
+    assert np.array_equal(got, want)
+    assert cnt.oob_reads == 0 and cnt.int_cast_oor == 0    # no undefined-behaviour inputs on golden scenes
+
+
+def test_frame_is_thread_count_independent(oracle, demo_scene, tex, sky, golden_frames):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 160, 120)
+    one, _, c1 = oracle.render(cam, demo_scene, tex, sky, 4, threads=1)
+    many, _, c2 = oracle.render(cam, demo_scene, tex, sky, 4, threads=0)
+    assert np.array_equal(one, many) and c1.as_dict() == c2.as_dict()
+
+
+def test_camera_and_raygen_bit_exact(oracle, golden_frames):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 160, 120)
+    assert bytes(cam) == golden_frames["camera_160x120"].tobytes()
+    rays = oracle.raygen(cam)
+    assert np.array_equal(rays.view(np.uint32), golden_frames["raygen_160x120"].view(np.uint32))
+
+
+def test_ray_counts_match_survey(oracle, demo_scene, tex, sky):
+    """depth 1 -> 7.00 rays/px (1 segment + 6 shadow rays when every primary ray hits)."""
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 160, 120)
+    _, _, c = oracle.render(cam, demo_scene, tex, sky, 1)
+    assert c.light_probes == 160 * 120              # every primary ray is probed against the lights
+    assert 0 <= 160 * 120 - c.segments < 20         # the few that see a light sphere directly end there
+    assert c.shadow_rays == 6 * c.shaded_hits
+    assert 6.9 < c.rays / (160 * 120) <= 7.0
+    _, _, c4 = oracle.render(cam, demo_scene, tex, sky, 4)
+    assert 13.0 < c4.rays / (160 * 120) < 14.0
+
+
+def test_strip_equals_rows_of_full_frame(oracle, demo_scene, tex, sky, golden_frames):
+    """Global ids under row-strip sharding: a strip is the same bits as the full frame's rows."""
+    w, h = 160, 120
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    full = golden_frames["render_map_160x120_d4"]
+    part, _, _ = oracle.render(cam, demo_scene, tex, sky, 4, id_begin=40 * w, id_end=88 * w)
+    assert np.array_equal(part, full[40 * w:88 * w])
+
+
+def test_unfused_path_equals_fused(oracle, demo_scene, tex, sky, golden_frames):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 160, 120)
+    rays = oracle.raygen(cam)
+    got, _ = oracle.trace_rays(rays, demo_scene, tex, sky, 4)
+    assert np.array_equal(got, golden_frames["render_map_160x120_d4"])
+
+
+# ---------------------------------------------------------------- per-function vectors
+def _inputs():
+    from oracle.gen_golden import make_vector_inputs
+    return make_vector_inputs()
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_vectors_intersect(oracle, golden_vectors):
+    d, g, L = _inputs(), golden_vectors, oracle.lib
+    t = C.c_float()
+    for i in range(len(d["sph_r"])):
+        hit = L.wo_intersect_sphere(_f3(d["sph_o"][i]), _f3(d["sph_d"][i]), _f3(d["sph_c"][i]), float(d["sph_r"][i]), C.byref(t))
+        assert hit == g["sphere_hit"][i] and np.float32(t.value).view(np.uint32) == g["sphere_t"][i].view(np.uint32)
+        hit = L.wo_intersect_plane(_f3(d["ray_o"][i]), _f3(d["ray_d"][i]), _f3(d["pl_n"][i]), _f3(d["pl_p"][i]), C.byref(t))
+        assert hit == g["plane_hit"][i] and np.float32(t.value).view(np.uint32) == g["plane_t"][i].view(np.uint32)
+    assert 0.3 < g["sphere_hit"].mean() < 0.9 and 0.2 < g["plane_hit"].mean() < 0.8   # both branches covered
+
+
+def test_vectors_optics(oracle, golden_vectors):
+    d, g, L = _inputs(), golden_vectors, oracle.lib
+    v = (C.c_float * 3)()
+    n = len(d["n12"])
+    refl, refr, sch = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    for i in range(n):
+        L.wo_reflect(_f3(d["inc"][i]), _f3(d["nrm"][i]), v); refl[i] = v[:]
+        L.wo_refract(float(d["n12"][i, 0]), float(d["n12"][i, 1]), _f3(d["inc"][i]), _f3(d["nrm"][i]), v); refr[i] = v[:]
+        sch[i] = L.wo_schlick(float(d["n12"][i, 0]), float(d["n12"][i, 1]), _f3(d["inc"][i]), _f3(d["nrm"][i]))
+    assert np.array_equal(_bits(refl), _bits(g["reflect"]))
+    nan = np.isnan(g["refract"][:, 0])
+    assert nan.any() and not nan.all()                    # total internal reflection is exercised
+    assert np.array_equal(np.isnan(refr[:, 0]), nan)
+    assert np.array_equal(_bits(refr[~nan]), _bits(g["refract"][~nan]))
+    assert np.array_equal(_bits(sch), _bits(g["schlick"]))
+
+
+def test_vectors_cube_rng_mod(oracle, golden_vectors):
+    d, g, L = _inputs(), golden_vectors, oracle.lib
+    uv = (C.c_int32 * 2)()
+    for i in range(len(d["dir"])):
+        L.wo_map_to_cube(_f3(d["dir"][i]), 1024, uv)
+        assert tuple(uv[:]) == tuple(g["cube_uv"][i])
+        s = C.c_uint32(int(d["seed"][i]))
+        val = L.wo_xorshift32(C.byref(s))
+        assert s.value == g["xorshift_state"][i] and np.float32(val).view(np.uint32) == g["xorshift_val"][i].view(np.uint32)
+        assert L.wo_euclidean_modulo(int(d["mod_a"][i]), int(d["mod_b"][i])) == g["emod"][i]
+    assert g["xorshift_val"][0] == 0.0 and g["xorshift_state"][0] == 0     # seed 0 is a fixed point
+    assert g["xorshift_val"].max() >= 2.0                                   # values reach [0,4), not [0,1)
+    assert (g["emod"] >= 0).all()
+
+
+def test_vectors_scene_queries(oracle, demo_scene, tex, sky, golden_vectors):
+    from oracle.oracle_py import _Inputs
+    d, g, L = _inputs(), golden_vectors, oracle.lib
+    inp = _Inputs(demo_scene, tex, sky)
+    v, pt, nm = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    mat = np.zeros(16, np.uint32)
+    n = len(d["seed"])
+    o_cam = np.array(CAM["origin"], np.float32)
+    planes = demo_scene.planes[:1].copy()
+    for i in range(n):
+        pl = planes.copy()
+        pl["normal"][0] = d["pl_n"][i]
+        pl["material"]["texture_id"][0] = i % 4
+        pl["material"]["texture_scale"][0] = np.float32(1 + (i % 7) * 16.5)
+        L.wo_plane_texture_pixel(pl.ctypes.data_as(C.c_void_p), _f3(d["tex_p"][i]), tex.ctypes.data_as(C.c_void_p),
+                                 tex.shape[2], tex.shape[1], tex.shape[0], v)
+        assert np.array_equal(_bits(np.array(v[:], np.float32)), _bits(g["plane_texel"][i]))
+        s = L.wo_shadow(_f3(d["sh_to"][i]), _f3(d["sh_from"][i]), C.byref(inp.c))
+        assert np.float32(s).view(np.uint32) == g["shadow"][i].view(np.uint32)
+        hit = L.wo_find_light(_f3(d["ray_o"][i]), _f3(g["light_dir"][i]), C.byref(inp.c), v)
+        assert hit == g["light_hit"][i]
+        assert np.array_equal(_bits(np.array(v[:], np.float32)), _bits(g["light_color"][i]))
+        hit = L.wo_find_solid(_f3(o_cam), _f3(d["ray_d"][i]), C.byref(inp.c), pt, nm, mat.ctypes.data_as(C.c_void_p))
+        assert hit == g["solid_hit"][i]
+        if hit:
+            assert np.array_equal(_bits(np.array(pt[:], np.float32)), _bits(g["solid_point"][i]))
+            assert np.array_equal(_bits(np.array(nm[:], np.float32)), _bits(g["solid_normal"][i]))
+            m = mat.copy(); m[3] = 0; m[14:] = 0
+            assert np.array_equal(m, g["solid_material"][i])
+    sh = g["shadow"]
+    assert (sh == 0).any() and (sh == 1).any() and ((sh > 0) & (sh < 1)).any()   # blocked / clear / through glass
+    assert g["light_hit"].sum() > 20 and g["solid_hit"].mean() > 0.3

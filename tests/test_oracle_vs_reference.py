@@ -1,0 +1,83 @@
+"""Pins the CPU restatement against the reference's OWN kernel sources compiled for the host
+(oracle/_ref/libref_cl.so, built in place from /root/reference by oracle/Makefile).
+Runs wherever that binary exists; everywhere else the committed fixtures carry the pin
+(test_oracle_golden.py).  Bar: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CAM, REFERENCE_ROOT, channel_diff
+
+
+@pytest.mark.parametrize("w,h,depth", [(96, 64, 1), (96, 64, 2), (96, 64, 3), (200, 150, 4), (96, 64, 8), (200, 150, 15)])
+def test_frames_bit_exact_against_reference_kernels(oracle, reference, demo_scene, tex, sky, w, h, depth):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    want, oob = reference.render(cam, demo_scene, tex, sky, depth)
+    got, _, cnt = oracle.render(cam, demo_scene, tex, sky, depth)
+    assert oob == 0 and cnt.oob_reads == 0
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("origin,look,fov", [((0.8, 2.5, -8.0), (0.0, 0.0, 1.0), 90.0),      # rayinteractive.c:111-115
+                                             ((-3.0, 0.6, 0.5), (1.0, 0.05, 0.3), 70.0),       # low, grazing the floor
+                                             ((0.8, 0.8, 1.5), (0.3, -0.2, 1.0), 100.0),       # camera INSIDE glass sphere #2
+                                             ((1.0, 9.0, 1.0), (0.01, -1.0, 0.02), 60.0)])    # looking down
+def test_other_cameras(oracle, reference, demo_scene, tex, sky, origin, look, fov):
+    cam = oracle.camera(origin, look, fov, 1.0, 128, 96)
+    want, _ = reference.render(cam, demo_scene, tex, sky, 15)
+    got, _, _ = oracle.render(cam, demo_scene, tex, sky, 15)
+    assert np.array_equal(got, want)
+
+
+def test_glass_field_scene(oracle, reference, tex, sky):
+    """Config C3's scene (64 dielectric spheres): deep refraction trees, total internal reflection."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.dielectric_field_scene(8)
+    cam = oracle.camera((3.5, 3.0, -6.0), (0.0, -2.5, 9.5), 90.0, 1.0, 96, 96)
+    want, _ = reference.render(cam, sc, tex, sky, 8)
+    got, _, cnt = oracle.render(cam, sc, tex, sky, 8)
+    assert np.array_equal(got, want)
+    assert cnt.pushes > 1000 and cnt.max_stack >= 4
+
+
+def test_textures_off_and_all_layers(oracle, reference, demo_scene, tex, sky):
+    from example_gui_opencl_raytracer_amd.scene import Scene
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 96, 64)
+    for tid in (-1, 0, 1, 3):
+        planes = demo_scene.planes.copy()
+        planes["material"]["texture_id"][0] = tid
+        sc = Scene(demo_scene.spheres, planes, demo_scene.lights)
+        want, _ = reference.render(cam, sc, tex, sky, 4)
+        got, _, cnt = oracle.render(cam, sc, tex, sky, 4)
+        assert np.array_equal(got, want)
+        assert (cnt.texel_fetches == 0) == (tid < 0)
+
+
+def test_raygen_bit_exact(oracle, reference):
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 200, 150)
+    assert np.array_equal(oracle.raygen(cam).view(np.uint32), reference.raygen(cam).view(np.uint32))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="reference tree absent")
+def test_against_the_references_committed_render(oracle, demo_scene):
+    """out/scene.png is the reference's only committed output: 800x600, depth 15, real assets,
+    rendered by the author on an unknown OpenCL GPU.  Statistical known-answer (SURVEY.md section 4
+    measured 88.5 % exact / 94.0 % within 1 LSB for the reference's own source built for the host,
+    all disagreement at shadow/texel/silhouette discontinuities)."""
+    from PIL import Image
+    from example_gui_opencl_raytracer_amd import api
+
+    def load(name):
+        return api.read_png(os.path.join(REFERENCE_ROOT, "assets", name))
+    tex = np.stack([load("cobblestone.png"), load("sand.png"), load("check.png"), load("grass.png")])   # raypng.c:74-78
+    sky = load("bg/stormydays.png")[None]                                                                  # raypng.c:80-81
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 800, 600)
+    got, _, cnt = oracle.render(cam, demo_scene, tex, sky, 15)
+    want_rgb = np.asarray(Image.open(os.path.join(REFERENCE_ROOT, "out", "scene.png")).convert("RGB")).reshape(-1, 3).astype(np.uint32)
+    want = (want_rgb[:, 0] << 16) | (want_rgb[:, 1] << 8) | want_rgb[:, 2]
+    d = channel_diff(got, want)
+    exact, le1 = (d == 0).mean(), (d <= 1).mean()
+    print(f"vs out/scene.png: exact {exact:.4f}, <=1 LSB {le1:.4f}, max {d.max()}, mean {d.mean():.4f}")
+    assert exact > 0.85 and le1 > 0.92 and d.mean() < 1.0
+    assert cnt.oob_reads == 0 and cnt.int_cast_oor == 0
