@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--strict", type=int, default=0, help="1: strict arithmetic build (parity build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--own-streams", action="store_true",
+                    help="experiment: each frame slot launches on its own stream, so consecutive frames overlap")
     ap.add_argument("--dump-png", default=None, help="rank 0 writes the assembled frame here")
     args = ap.parse_args()
 
@@ -93,7 +95,10 @@ def main():
     tex, sky = textures.texture_layers(), textures.skybox_cross(4096)
     H = H_PER_GPU * world
     px_rank = W * H_PER_GPU
-    stream = torch.cuda.current_stream()
+    # every launch of this rank goes to ONE explicit HIP stream that torch also treats as current, so the
+    # shim's hipEvents, torch's collectives and the synchronisation around the timed region agree
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
 
     # two frame slots: the gather of frame k overlaps the trace of frame k+1
     fbs = [torch.zeros(px_rank, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -101,7 +106,8 @@ def main():
     for fb in fbs:
         r = Renderer(sc, tex, sky, W, H, depth=DEPTH, strict=bool(args.strict),
                      bands=(world, rank) if world > 1 else None, framebuffer_ptr=fb.data_ptr())
-        r.w.set_stream(stream.cuda_stream)
+        if not args.own_streams:
+            r.w.set_stream(stream.cuda_stream)
         r.look(**pkg.CAMERA_RAYPNG)
         r.w.set_async(True)
         rr.append(r)

@@ -34,7 +34,8 @@ extern "C" hipError_t wt_strict_launch_raygen(const raygen_params*, hipStream_t)
 namespace {
 
 enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8 }; /* = WT_F_* of whitted_trace.inc */
-constexpr unsigned BLOCK = 256;       /* work-group size; also the reference's rounding unit (opencl_wrap.c:374) */
+constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
+constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
 constexpr int LDS_LEVELS = 3;
 
@@ -382,10 +383,10 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     }
     unsigned grid;
     if (P.tiled) {
-        unsigned trows = (P.rows + 7) / 8, tpr = (P.width + 31) / 32;
+        unsigned trows = (P.rows + 7) / 8, tpr = (P.width + 7) / 8;
         grid = 8 * ((trows + 7) / 8) * tpr;
     } else {
-        grid = (P.n_items + BLOCK - 1) / BLOCK;
+        grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
     LaunchTimer t(I, kid);
     hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)

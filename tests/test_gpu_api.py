@@ -98,11 +98,14 @@ def test_external_framebuffer_and_stream(R, demo_scene, tex, sky):
     import torch
     w, h = 160, 120
     fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
     r = R(demo_scene, tex, sky, w, h, depth=4, strict=True, framebuffer_ptr=fb.data_ptr())
-    r.w.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.w.set_stream(side.cuda_stream)
+    r.w.set_async(True)
     r.look(**CAM)
     r.render(readback=False)
-    torch.cuda.synchronize()
+    side.synchronize()
     own = R(demo_scene, tex, sky, w, h, depth=4, strict=True)
     own.look(**CAM)
     assert np.array_equal(fb.cpu().numpy().view(np.uint32), own.render())

@@ -64,16 +64,32 @@ def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
 
 
 # ------------------------------------------------------------ other scenes / cameras vs the oracle
-@pytest.mark.parametrize("origin,look,fov", [((0.8, 2.5, -8.0), (0.0, 0.0, 1.0), 90.0),
-                                             ((-3.0, 0.6, 0.5), (1.0, 0.05, 0.3), 70.0),
-                                             ((0.8, 0.8, 1.5), (0.3, -0.2, 1.0), 100.0),     # inside a glass sphere
-                                             ((1.0, 9.0, 1.0), (0.01, -1.0, 0.02), 60.0)])
+CAMERAS = [((0.8, 2.5, -8.0), (0.0, 0.0, 1.0), 90.0),        # rayinteractive.c:111-115
+           ((-3.0, 0.6, 0.5), (1.0, 0.05, 0.3), 70.0),       # low, grazing the floor
+           ((0.9, 0.7, 1.4), (0.3, -0.2, 1.0), 100.0),       # inside glass sphere #2
+           ((1.0, 9.0, 1.0), (0.01, -1.0, 0.02), 60.0)]      # looking down
+
+
+@pytest.mark.parametrize("origin,look,fov", CAMERAS)
 def test_cameras(R, oracle, demo_scene, tex, sky, origin, look, fov):
     w, h, depth = 128, 96, 15
     cam = dict(origin=origin, look=look, fov=fov, focal=1.0)
     want, _, _ = oracle.render(oracle.camera(origin, look, fov, 1.0, w, h), demo_scene, tex, sky, depth)
     check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
     check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
+
+
+def test_degenerate_camera_nan_propagation(R, oracle, demo_scene, tex, sky):
+    """Camera at the exact centre of glass sphere #2: view and light directions cancel exactly for half the
+    pixels, normalize(0) = NaN poisons the radiance and the pack turns it into 0 (clamp of NaN).  The strict
+    build must reproduce that bit for bit.  (The fast build legitimately differs here: a 1-ulp change removes
+    the exact cancellation, so it is not compared.)"""
+    w, h, depth = 128, 96, 15
+    origin, look, fov = (0.8, 0.8, 1.5), (0.3, -0.2, 1.0), 100.0
+    want, rgb, _ = oracle.render(oracle.camera(origin, look, fov, 1.0, w, h), demo_scene, tex, sky, depth, want_rgb=True)
+    assert np.isnan(rgb).any()
+    got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=dict(origin=origin, look=look, fov=fov, focal=1.0))
+    check(got, want, 0.999)
 
 
 @pytest.mark.parametrize("depth", [1, 2, 4, 5, 8, 15, 32])
@@ -93,7 +109,7 @@ def test_glass_field_divergence_scene(R, oracle, tex, sky):
     cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
     w, h, depth = 256, 256, 8
     want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
-    assert cnt.pushes > 10000 and cnt.tir_drops > 0
+    assert cnt.pushes > 10000 and cnt.max_stack >= 4
     check(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
     check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.98, 0.99)
 
@@ -183,8 +199,11 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
         rays = c["segments"] + c["shadow_rays"]
         assert abs(rays - cnt.rays) <= (0 if strict else 2e-4 * cnt.rays)
         if strict:
-            assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"], c["texel_fetches"]) == \
-                   (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches, cnt.texel_fetches)
+            assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"]) == \
+                   (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches)
+            # the reference fetches a texel for every plane that improves t (primitives.cl:374-378); the
+            # kernel fetches it for the winning plane only -- same image, fewer fetches
+            assert 0 < c["texel_fetches"] <= cnt.texel_fetches
 
 
 def test_large_frame_is_deterministic_and_tile_order_free(R, tex, sky):

@@ -1,0 +1,25 @@
+"""Condense a tools/profile_round.sh output directory into small text files for profiles/."""
+import collections, csv, glob, os, sys
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+out = []
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    out.append(f"## rocprofv3 --kernel-trace --stats ({os.path.basename(f)})\n")
+    out.append(open(f).read())
+pm = collections.OrderedDict()
+info = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "wt_trace" not in k or "<5>" in k or "<7>" in k:     # skip the one-off counting build
+            continue
+        pm.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+        info[k] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+out.append("\n## rocprofv3 --pmc (separate passes), per-dispatch mean over the timed launches\n")
+for k, v in info.items():
+    out.append(f"kernel {k}: {v}\n")
+out.append("counter,mean_per_dispatch,dispatches\n")
+for (k, c), v in pm.items():
+    out.append(f"{c},{sum(v) / len(v):.1f},{len(v)}\n")
+open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("".join(out))
+print("".join(out))
