@@ -30,6 +30,7 @@ extern "C" hipError_t wt_fast_launch_trace(const whitted_params*, int, unsigned,
 extern "C" hipError_t wt_fast_launch_raygen(const raygen_params*, hipStream_t);
 extern "C" hipError_t wt_strict_launch_trace(const whitted_params*, int, unsigned, size_t, hipStream_t);
 extern "C" hipError_t wt_strict_launch_raygen(const raygen_params*, hipStream_t);
+extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, hipStream_t);
 
 namespace {
 
@@ -116,6 +117,12 @@ struct Impl {
     float* d_geom = nullptr; size_t geom_f4 = 0;
     float* d_ptex = nullptr;
     unsigned long long* d_counters = nullptr;
+    /* cost-sorted tile dispatch: costs written by frame n order the tiles of frame n+1 */
+    int sched = 1;
+    unsigned* d_tile_cost = nullptr; unsigned* d_tile_order = nullptr;
+    uint32_t sched_w = 0, sched_rows = 0;
+    bool sched_valid = false;
+    RaygenArgs sched_sig{}; int sched_sig_depth = 0; const void* sched_sig_scene = nullptr;
     /* timing log */
     std::vector<TimingEntry> timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -382,9 +389,28 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
         P.counters = I->d_counters;
     }
     unsigned grid;
+    bool sched_rebuild = false;
+    unsigned trows = 0, tpr = 0, per_share = 0;
     if (P.tiled) {
-        unsigned trows = (P.rows + 7) / 8, tpr = (P.width + 7) / 8;
-        grid = 8 * ((trows + 7) / 8) * tpr;
+        trows = (P.rows + 7) / 8; tpr = (P.width + 7) / 8;
+        per_share = ((trows + 7) / 8) * tpr;
+        grid = 8 * per_share;
+        if (I->sched && !(I->variant & 4)) {
+            if (I->sched_w != P.width || I->sched_rows != P.rows || !I->d_tile_cost) {
+                if (I->d_tile_cost) (void)hipFree(I->d_tile_cost);
+                if (I->d_tile_order) (void)hipFree(I->d_tile_order);
+                HIP_OK(hipMalloc((void**)&I->d_tile_cost, (size_t)trows * tpr * 4), "Couldn't allocate device memory");
+                HIP_OK(hipMalloc((void**)&I->d_tile_order, (size_t)grid * 4), "Couldn't allocate device memory");
+                I->sched_w = P.width; I->sched_rows = P.rows; I->sched_valid = false;
+            }
+            P.tile_cost = I->d_tile_cost;
+            P.tile_order = I->sched_valid ? I->d_tile_order : nullptr;
+            /* the costs can only change when the camera, the depth or the scene did */
+            const RaygenArgs& g = rays->gen;
+            sched_rebuild = !I->sched_valid || memcmp(&g, &I->sched_sig, sizeof g) != 0 || I->sched_sig_depth != I->depth ||
+                            I->sched_sig_scene != (const void*)I->d_geom;
+            if (sched_rebuild) { I->sched_sig = g; I->sched_sig_depth = I->depth; I->sched_sig_scene = I->d_geom; }
+        }
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
@@ -393,6 +419,11 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
     if (e != hipSuccess) die("Couldn't run the kernel");
     t.done();
+    if (sched_rebuild) {
+        if (wt_fast_launch_sched(I->d_tile_cost, I->d_tile_order, tpr, trows, per_share, I->stream) != hipSuccess)
+            die("Couldn't run the kernel");
+        I->sched_valid = true;
+    }
 }
 
 void run_raygen(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
@@ -576,6 +607,8 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_geom) (void)hipFree(I->d_geom);
     if (I->d_ptex) (void)hipFree(I->d_ptex);
     if (I->d_counters) (void)hipFree(I->d_counters);
+    if (I->d_tile_cost) (void)hipFree(I->d_tile_cost);
+    if (I->d_tile_order) (void)hipFree(I->d_tile_order);
     for (auto& t : I->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto& p : I->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (I->own_stream) (void)hipStreamDestroy(I->own_stream);
@@ -603,6 +636,7 @@ void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {
     Impl* I = impl_of(wrap);
     I->stream = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
 }
+void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; I->sched_valid = false; }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
 

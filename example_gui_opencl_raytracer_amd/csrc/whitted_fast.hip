@@ -11,4 +11,5 @@
 #define WT_NS wt_fast
 #define WT_LAUNCH_TRACE wt_fast_launch_trace
 #define WT_LAUNCH_RAYGEN wt_fast_launch_raygen
+#define WT_LAUNCH_SCHED wt_fast_launch_sched
 #include "whitted_launch.inc"

@@ -32,6 +32,11 @@ typedef struct {
     /* interleaved 8-row bands (multi-GPU load balance): local row y is global row
      * ((y/8)*band_stride + band_phase)*8 + y%8; band_stride <= 1 = contiguous range        */
     uint32_t band_stride, band_phase;
+    /* cost-sorted tile dispatch (tiled mode; both nullable): tile_order[b] = tile served by workgroup b
+     * (row-major tile index, 0xFFFFFFFF = none), heaviest tiles of the previous frame first, one list per
+     * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */
     const float* geom;     /* float4 stream, layout above                             */

@@ -11,4 +11,5 @@
 #define WT_NS wt_strict
 #define WT_LAUNCH_TRACE wt_strict_launch_trace
 #define WT_LAUNCH_RAYGEN wt_strict_launch_raygen
+#define WT_LAUNCH_SCHED wt_strict_launch_sched
 #include "whitted_launch.inc"

@@ -88,6 +88,11 @@ void clw_ext_set_debug_rgb(cl_wrap* wrap, void* device_ptr_f32x3);
 void clw_ext_enable_counters(cl_wrap* wrap, int enable);
 void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
 
+/* Cost-sorted tile dispatch (default on): every 8x8 tile reports its cost, and the next frame serves each
+ * XCD's tiles heaviest-first, so the expensive refraction tiles no longer end up in the tail of the launch.
+ * Pure scheduling: the image is bit-identical either way. */
+void clw_ext_set_tile_sched(cl_wrap* wrap, int on);
+
 /* Kernel build variant for A/B measurements; 0 = default. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 

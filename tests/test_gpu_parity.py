@@ -139,6 +139,27 @@ def test_lds_and_global_geometry_paths_agree_exactly(R, demo_scene, tex, sky):
         assert np.array_equal(o, outs[0])
 
 
+def test_cost_sorted_dispatch_is_pure_scheduling(R, demo_scene, tex, sky):
+    """Frame 1 runs in the default tile order and records tile costs; frames 2+ serve each XCD's tiles
+    heaviest-first.  Same bits in every case, also after the camera moves and with scheduling off."""
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    w, h = 328, 203                                   # ragged: 41 tile columns, 26 tile rows (25.4)
+    cams = [CAM, dict(origin=(1.5, 2.0, -6.0), look=(-0.1, -0.1, 1.0), fov=90.0, focal=1.0)]
+    ref = []
+    off = Renderer(demo_scene, tex, sky, w, h, depth=15, strict=True)
+    off.w.set_tile_sched(0)
+    for cam in cams:
+        off.look(**cam)
+        ref.append(off.render())
+    off.release()
+    on = Renderer(demo_scene, tex, sky, w, h, depth=15, strict=True)
+    for cam, want in zip(cams + cams, ref + ref):
+        on.look(**cam)
+        for _ in range(3):
+            assert np.array_equal(on.render(), want)
+    on.release()
+
+
 # ------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (33, 9), (150, 101), (257, 8)])
 def test_ragged_sizes(R, oracle, demo_scene, tex, sky, w, h):
