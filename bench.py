@@ -80,10 +80,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--own-streams", action="store_true",
                     help="experiment: each frame slot launches on its own stream, so consecutive frames overlap")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a ONE-GPU box: gloo backend, all ranks on cuda:0 (checks the sharded path, not RCCL)")
     ap.add_argument("--dump-png", default=None, help="rank 0 writes the assembled frame here")
     args = ap.parse_args()
 
-    rank, world, local_rank = D.init_process_group()
+    rank, world, local_rank = D.init_process_group("gloo" if args.rehearse else None)
+    if args.rehearse:
+        local_rank = 0          # every rank on cuda:0, gathers staged through the CPU (no RCCL on one GPU)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -111,24 +115,19 @@ def main():
         r.look(**pkg.CAMERA_RAYPNG)
         r.w.set_async(True)
         rr.append(r)
-    parts = [[torch.empty(px_rank, dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(2)] \
-        if (world > 1 and rank == 0) else [None, None]
-    pending = [None, None]
+    gat = D.BandGatherer(W, H, rank, world, dev, staged_on_cpu=args.rehearse)
 
     def step(k):
         s = k & 1
-        if pending[s] is not None:
-            pending[s].wait()                      # frame k-2 has left this slot
-            pending[s] = None
+        gat.wait(s)                                # frame k-2 has left this slot
         rr[s].render(readback=False)               # raygen latch + trace launch (async, torch's stream)
         if world > 1:
-            pending[s] = torch.distributed.gather(fbs[s], gather_list=parts[s], dst=0, async_op=True)
+            if args.rehearse:
+                torch.cuda.current_stream().synchronize()
+            gat.gather_async(s, fbs[s])
 
     def drain():
-        for s in (0, 1):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
+        gat.drain()
 
     def barrier():
         if world > 1:
@@ -188,8 +187,7 @@ def main():
         if world == 1:
             full = fbs[(args.steps - 1) & 1].cpu().numpy().view(np.uint32)
         else:
-            nb = H // (8 * world)
-            full = torch.stack([p.view(nb, 8 * W) for p in parts[(args.steps - 1) & 1]], 1).reshape(-1).cpu().numpy().view(np.uint32)
+            full = gat.assemble((args.steps - 1) & 1).cpu().numpy().view(np.uint32)
         api.write_png(args.dump_png, full, W, H)
 
     if rank == 0:

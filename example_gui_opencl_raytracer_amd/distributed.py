@@ -59,3 +59,41 @@ def gather_strips(strip: torch.Tensor, width: int, height: int, rank: int, world
         r0, rows = strip_rows(height, world, r)
         full[r0 * width:(r0 + rows) * width] = parts[r][: rows * width]
     return full
+
+
+class BandGatherer:
+    """One gather per frame of every rank's interleaved 8-row bands to rank 0, with two frame slots so
+    the gather of frame k overlaps the trace of frame k+1 (the work handle is waited on before the slot
+    is reused).  Rank r owns bands r, r+world, r+2*world, ... (renderer `bands=(world, rank)`), so rank 0
+    receives `world` equal blocks and the full frame is their interleave."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, dtype=torch.int32, staged_on_cpu=False):
+        assert height % (8 * world) == 0, "interleaved bands need height % (8 * world) == 0"
+        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.px_rank = width * height // world
+        self.staged = staged_on_cpu           # rehearsal with gloo: collectives on CPU copies
+        dev = torch.device("cpu") if staged_on_cpu else device
+        self.parts = [[torch.empty(self.px_rank, dtype=dtype, device=dev) for _ in range(world)] if rank == 0 else None
+                      for _ in range(2)]
+        self.pending = [None, None]
+
+    def wait(self, slot: int) -> None:
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+
+    def gather_async(self, slot: int, share: torch.Tensor) -> None:
+        if self.world == 1:
+            return
+        send = share.cpu() if self.staged else share
+        self.pending[slot] = dist.gather(send, gather_list=self.parts[slot], dst=0, async_op=True)
+
+    def drain(self) -> None:
+        self.wait(0)
+        self.wait(1)
+
+    def assemble(self, slot: int) -> torch.Tensor:
+        """Rank 0: the full frame [height * width] of the last frame gathered into `slot`."""
+        assert self.rank == 0
+        nb = self.height // (8 * self.world)                      # bands per rank
+        return torch.stack([p.view(nb, 8 * self.width) for p in self.parts[slot]], 1).reshape(-1)

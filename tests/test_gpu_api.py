@@ -93,6 +93,23 @@ def test_row_strips_are_bit_identical_to_the_full_frame(R, demo_scene, tex, sky,
             s.release()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_interleaved_bands_are_bit_identical_to_the_full_frame(R, demo_scene, tex, sky, world):
+    """bench.py's sharding: rank r renders every world-th 8-row band with global ids."""
+    w, h, depth = 200, 16 * world, 4
+    full = R(demo_scene, tex, sky, w, h, depth=depth, strict=False)
+    full.look(**CAM)
+    want = full.render().reshape(h // 8, 8 * w)
+    full.release()
+    for rank in range(world):
+        for fuse in (True, False):
+            s = R(demo_scene, tex, sky, w, h, depth=depth, strict=False, bands=(world, rank), fuse=fuse)
+            s.look(**CAM)
+            got = s.render().reshape(-1, 8 * w)
+            assert np.array_equal(got, want[rank::world])
+            s.release()
+
+
 def test_external_framebuffer_and_stream(R, demo_scene, tex, sky):
     """bench.py's plumbing: torch owns the framebuffer and the stream, the shim renders into it."""
     import torch

@@ -59,3 +59,42 @@ def test_single_rank_gather_is_identity():
     from example_gui_opencl_raytracer_amd import distributed as D
     t = torch.arange(12, dtype=torch.int32)
     assert D.gather_strips(t, 4, 3, 0, 1) is t
+
+
+def _band_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from example_gui_opencl_raytracer_amd import distributed as D, scene, textures
+    from oracle.oracle_py import Oracle
+    D.init_process_group("gloo")
+    o = Oracle()
+    sc, tex, sky = scene.render_map_scene(), textures.texture_layers(), textures.skybox_cross(512)
+    w, h = 96, 16 * world * 2                       # height % (8 * world) == 0
+    cam = o.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    # rank r owns bands r, r + world, ...: band b = rows [8b, 8b + 8) with GLOBAL ids
+    share = np.concatenate([o.render(cam, sc, tex, sky, DEPTH, id_begin=8 * b * w, id_end=8 * (b + 1) * w, threads=1)[0]
+                            for b in range(rank, h // 8, world)])
+    gat = D.BandGatherer(w, h, rank, world, torch.device("cpu"))
+    for frame in range(3):                          # both slots, and reuse of slot 0
+        gat.wait(frame & 1)
+        gat.gather_async(frame & 1, torch.from_numpy(share.view(np.int32)))
+    gat.drain()
+    dist.barrier()
+    if rank == 0:
+        assert torch.equal(gat.assemble(0), gat.assemble(1))
+        np.save(out_path, gat.assemble(0).numpy().view(np.uint32))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_interleaved_bands_gather_to_the_single_rank_frame(oracle, demo_scene, tex, sky, tmp_path, world):
+    """bench.py's multi-GPU path: interleaved 8-row bands + BandGatherer (double-buffered async gather)."""
+    out = str(tmp_path / f"bands_{world}.npy")
+    mp.spawn(_band_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    w, h = 96, 16 * world * 2
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    want, _, _ = oracle.render(cam, demo_scene, tex, sky, DEPTH)
+    assert np.array_equal(got, want)
