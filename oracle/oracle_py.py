@@ -26,7 +26,7 @@ def build(ref: bool = True) -> None:
     """Compile the checker (gcc; and, where /root/reference exists, the _ref build)."""
     subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True)
     if ref:   # both are no-ops where /root/reference does not exist (the GPU box keeps the prebuilt binaries)
-        subprocess.run(["make", "-s", "-C", HERE, "ref", "raypng"], check=True)
+        subprocess.run(["make", "-s", "-C", HERE, "ref", "raypng", "rayinteractive"], check=True)
 
 
 class Camera(C.Structure):
