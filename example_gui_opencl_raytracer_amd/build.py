@@ -13,6 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+ROOT_DIR = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libopencl_wrap_hip.so")
 ARCH = "gfx950"
@@ -66,6 +67,16 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra_devic
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    if not tag:      # the pure-C bench driver (host side in the reference's language), linked against the shim
+        exe = os.path.join(ROOT_DIR, "tools", "raybench")
+        src = os.path.join(ROOT_DIR, "tools", "raybench.c")
+        if force or _newer(exe, [src, lib]):
+            cmd = [CC, "-O2", "-std=c99", "-D_DEFAULT_SOURCE", "-DCL_TARGET_OPENCL_VERSION=300", "-Wall", "-I", os.path.join(ROOT_DIR, "include"),
+                   src, "-o", exe, "-L", HERE, "-lopencl_wrap_hip", "-Wl,-rpath,$ORIGIN/../example_gui_opencl_raytracer_amd",
+                   "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
     return lib
 
 

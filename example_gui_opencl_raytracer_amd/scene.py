@@ -107,6 +107,18 @@ class Scene:
 
     @staticmethod
     def from_bytes(buf: bytes) -> "Scene":
+        if buf[:8] == Scene.EXT_MAGIC:
+            if len(buf) < 20:
+                raise ValueError("truncated scene archive")
+            counts = np.frombuffer(buf, "<u4", 3, 8)
+            off, out = 20, []
+            for n, dt in zip(counts, (SPHERE, PLANE, LIGHT)):
+                end = off + int(n) * dt.itemsize
+                if end > len(buf):
+                    raise ValueError("truncated scene archive")
+                out.append(np.frombuffer(buf, dtype=dt, count=int(n), offset=off).copy())
+                off = end
+            return Scene(*out)
         off = 0
         out = []
         for dt in (SPHERE, PLANE, LIGHT):
@@ -121,9 +133,22 @@ class Scene:
             off = end
         return Scene(*out)
 
-    def save(self, path):
+    # ---- extended archive: the one-byte counts cap a scene at 255 primitives per
+    #      type.  Layout: 8-byte magic, three little-endian u32 counts, then the same raw struct arrays.
+    #      Legacy files (first byte = sphere count) remain valid input everywhere.
+    EXT_MAGIC = b"\xffRMAPv2\x00"
+
+    def to_bytes_ext(self) -> bytes:
+        ns, np_, nl = self.counts
+        return (self.EXT_MAGIC + np.array([ns, np_, nl], "<u4").tobytes() + self.spheres.tobytes()
+                + self.planes.tobytes() + self.lights.tobytes())
+
+    def save(self, path, ext: bool | None = None):
+        """ext=None: legacy format when the counts fit one byte, extended otherwise."""
+        if ext is None:
+            ext = max(self.counts) > 255
         with open(path, "wb") as f:
-            f.write(self.to_bytes())
+            f.write(self.to_bytes_ext() if ext else self.to_bytes())
 
     @staticmethod
     def load(path) -> "Scene":

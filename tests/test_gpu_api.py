@@ -253,3 +253,34 @@ def test_unchanged_rayinteractive_driver_runs_headless(oracle, demo_scene, tex, 
     assert (d == 0).mean() >= 0.995 and (d <= 1).mean() >= 0.998
     moved = run("WWWWllllSZ", 40, "moved.png")               # forward x4, turn left x4, back, down ... cycled
     assert (channel_diff(moved, still) > 8).mean() > 0.2     # the camera really moved
+
+
+RAYBENCH = os.path.join(ROOT, "tools", "raybench")
+
+
+@pytest.mark.skipif(not os.path.exists(RAYBENCH), reason="tools/raybench not built")
+def test_pure_c_bench_driver(oracle, demo_scene, tex, tmp_path):
+    """tools/raybench.c: host side in C, sizes as size_t, both scene archive formats, PNG out."""
+    import json
+    from example_gui_opencl_raytracer_amd import api, scene, textures
+    sky = textures.skybox_cross(512)
+    _scratch_tree(tmp_path, demo_scene, tex, sky)
+    p = subprocess.run([RAYBENCH, "-w", "320", "-h", "200", "-d", "4", "-n", "5", "-S", "-o", "out/c.png"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["frame"] == "320x200" and line["spheres"] == 4 and line["trace_kernel_ms"] > 0
+    img = api.read_png(str(tmp_path / "out" / "c.png"))
+    got = (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
+    want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 320, 200), demo_scene, tex, sky, 4)
+    assert (channel_diff(got, want) == 0).mean() >= 0.999
+    big = scene.sphere_grid_scene(20, 20)                           # 400 spheres: extended archive + wide counts
+    big.save(tmp_path / "scenes" / "big.map")
+    p = subprocess.run([RAYBENCH, "-w", "96", "-h", "64", "-d", "2", "-n", "2", "-S", "-s", "scenes/big.map", "-o", "out/b.png"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert json.loads(p.stdout.strip().splitlines()[-1])["spheres"] == 400
+    img = api.read_png(str(tmp_path / "out" / "b.png"))
+    got = (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
+    want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 96, 64), big, tex, sky, 2)
+    assert (channel_diff(got, want) == 0).mean() >= 0.999

@@ -54,6 +54,20 @@ def test_regenerated_scene_equals_committed_render_map(demo_scene):
         assert np.array_equal(np.concatenate(fields(mine), 1), np.concatenate(fields(theirs), 1))
 
 
+def test_extended_archive_roundtrip(demo_scene, tmp_path):
+    big = S.sphere_grid_scene(20, 20)
+    blob = big.to_bytes_ext()
+    assert blob[:8] == S.Scene.EXT_MAGIC and len(blob) == 20 + 400 * 96 + 96 + 3 * 48
+    assert S.Scene.from_bytes(blob).to_bytes_ext() == blob
+    p = tmp_path / "big.map"
+    big.save(p)                                   # picks the extended format on its own
+    assert S.Scene.load(p).counts == (400, 1, 3)
+    small = S.Scene.from_bytes(demo_scene.to_bytes_ext())      # small scenes may use it too
+    assert small.to_bytes() == demo_scene.to_bytes()
+    with pytest.raises(ValueError):
+        S.Scene.from_bytes(blob[:1000])
+
+
 def test_benchmark_scene_generators():
     c3 = S.dielectric_field_scene(8)
     assert c3.counts == (64, 1, 3) and (c3.spheres["material"]["transperent"] == 1).all()
