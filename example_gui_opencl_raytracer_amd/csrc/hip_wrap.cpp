@@ -34,11 +34,13 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 
 namespace {
 
-enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8 }; /* = WT_F_* of whitted_trace.inc */
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16 }; /* = WT_F_* of whitted_trace.inc */
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
 constexpr int LDS_LEVELS = 3;
+constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes with more spheres than fit one-byte counts get the uniform grid */
+constexpr size_t GRID_MAX_PAIRS = (size_t)1 << 27;
 
 [[noreturn]] void die(const char* fmt, ...) {
     va_list ap;
@@ -116,6 +118,8 @@ struct Impl {
     uint32_t prep_ns = 0, prep_np = 0, prep_nl = 0;
     float* d_geom = nullptr; size_t geom_f4 = 0;
     float* d_ptex = nullptr;
+    uint32_t *d_grid_start = nullptr, *d_grid_items = nullptr, *d_grid_box = nullptr;
+    wprep_grid grid{}; bool grid_ok = false; int use_grid = 1;
     unsigned long long* d_counters = nullptr;
     /* cost-sorted tile dispatch: costs written by frame n order the tiles of frame n+1 */
     int sched = 1;
@@ -300,6 +304,23 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     HIP_OK(hipMalloc((void**)&I->d_ptex, ptex.size() * 4), "Couldn't allocate device memory");
     HIP_OK(hipMemcpy(I->d_geom, geom.data(), geom.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
     HIP_OK(hipMemcpy(I->d_ptex, ptex.data(), ptex.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    /* uniform grid over the spheres for big scenes */
+    for (uint32_t** q : {&I->d_grid_start, &I->d_grid_items, &I->d_grid_box}) { if (*q) { (void)hipFree(*q); *q = nullptr; } }
+    I->grid_ok = false;
+    if (ns > GRID_MIN_SPHERES) {
+        size_t pairs = wprep_grid_plan(hs, ns, &I->grid);
+        if (pairs <= GRID_MAX_PAIRS) {
+            std::vector<uint32_t> st((size_t)I->grid.ncells + 1), it(pairs ? pairs : 1), bx(2 * (size_t)ns);
+            wprep_grid_fill(hs, ns, &I->grid, st.data(), it.data(), bx.data());
+            HIP_OK(hipMalloc((void**)&I->d_grid_start, st.size() * 4), "Couldn't allocate device memory");
+            HIP_OK(hipMalloc((void**)&I->d_grid_items, it.size() * 4), "Couldn't allocate device memory");
+            HIP_OK(hipMalloc((void**)&I->d_grid_box, bx.size() * 4), "Couldn't allocate device memory");
+            HIP_OK(hipMemcpy(I->d_grid_start, st.data(), st.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+            HIP_OK(hipMemcpy(I->d_grid_items, it.data(), it.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+            HIP_OK(hipMemcpy(I->d_grid_box, bx.data(), bx.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+            I->grid_ok = true;
+        }
+    }
     I->geom_f4 = f4;
     I->prep_s = s; I->prep_p = p; I->prep_l = l; I->prep_ns = ns; I->prep_np = np; I->prep_nl = nl;
 }
@@ -379,7 +400,13 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     }
     if (I->depth > LDS_LEVELS + 1) flags |= F_DEEP;
     size_t dyn_lds = 0;
-    if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
+    if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
+        flags |= F_GRID;
+        P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box;
+        for (int a = 0; a < 3; a++) {
+            P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
+        }
+    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
     if (I->counting) {
         flags |= F_COUNT;
         if (!I->d_counters) {
@@ -607,6 +634,7 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_geom) (void)hipFree(I->d_geom);
     if (I->d_ptex) (void)hipFree(I->d_ptex);
     if (I->d_counters) (void)hipFree(I->d_counters);
+    for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
     if (I->d_tile_cost) (void)hipFree(I->d_tile_cost);
     if (I->d_tile_order) (void)hipFree(I->d_tile_order);
     for (auto& t : I->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -636,6 +664,7 @@ void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {
     Impl* I = impl_of(wrap);
     I->stream = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
 }
+void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 : 0; }
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; I->sched_valid = false; }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }

@@ -11,6 +11,8 @@
  */
 #include "scene_prep.h"
 #include <string.h>
+#include <math.h>
+#include <stdlib.h>
 
 #define INV_PI_F 0.31830988618379067154f
 
@@ -77,4 +79,96 @@ void wprep_build(const uint8_t* spheres, uint32_t ns, const uint8_t* planes, uin
         }
         g[7] = r;
     }
+}
+
+/* ---- uniform grid ---------------------------------------------------------------------------------- */
+static void sphere_cells(const uint8_t* s, const wprep_grid* g, int lo[3], int hi[3]) {
+    float r = ldf(s, 16);
+    for (int a = 0; a < 3; a++) {
+        float c = ldf(s, 4 * (size_t)a);
+        /* conservative: the box is widened by a margin far larger than the traversal's rounding error */
+        float pad = 1e-3f * g->cell[a] + 1e-5f * (fabsf(c) + r);
+        int l = (int)floorf((c - r - pad - g->gmin[a]) * g->inv[a]);
+        int h = (int)floorf((c + r + pad - g->gmin[a]) * g->inv[a]);
+        lo[a] = l < 0 ? 0 : (l >= g->res[a] ? g->res[a] - 1 : l);
+        hi[a] = h < 0 ? 0 : (h >= g->res[a] ? g->res[a] - 1 : h);
+    }
+}
+
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, wprep_grid* g) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < ns; i++) {
+        const uint8_t* s = spheres + 96 * (size_t)i;
+        float r = ldf(s, 16);
+        for (int a = 0; a < 3; a++) {
+            float c = ldf(s, 4 * (size_t)a);
+            if (c - r < mn[a]) mn[a] = c - r;
+            if (c + r > mx[a]) mx[a] = c + r;
+        }
+    }
+    float ext[3], vol = 1.0f, big = 0.0f;
+    for (int a = 0; a < 3; a++) { ext[a] = mx[a] - mn[a]; if (ext[a] > big) big = ext[a]; }
+    if (!(big > 0.0f)) big = 1.0f;
+    for (int a = 0; a < 3; a++) {
+        float pad = 1e-2f * big + 1e-3f;        /* every sphere lies strictly inside the grid bounds */
+        mn[a] -= pad; mx[a] += pad; ext[a] = mx[a] - mn[a];
+        vol *= ext[a];
+    }
+    /* about one sphere per cell, cubic cells, 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
+    float side = cbrtf(vol / (float)(ns ? ns : 1));
+    uint64_t total = 1;
+    for (int a = 0; a < 3; a++) {
+        int n = (int)(ext[a] / side + 0.5f);
+        if (n < 1) n = 1;
+        if (n > 1024) n = 1024;
+        g->res[a] = n;
+        total *= (uint64_t)n;
+    }
+    while (total > (1u << 22)) {                /* coarsen the finest axes until the table fits */
+        int a = 0;
+        for (int k = 1; k < 3; k++) if (g->res[k] > g->res[a]) a = k;
+        total /= (uint64_t)g->res[a];
+        g->res[a] = (g->res[a] + 1) / 2;
+        total *= (uint64_t)g->res[a];
+    }
+    for (int a = 0; a < 3; a++) {
+        g->gmin[a] = mn[a];
+        g->cell[a] = ext[a] / (float)g->res[a];
+        g->inv[a] = 1.0f / g->cell[a];
+    }
+    g->ncells = (uint32_t)total;
+    size_t pairs = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+        int lo[3], hi[3];
+        sphere_cells(spheres + 96 * (size_t)i, g, lo, hi);
+        pairs += (size_t)(hi[0] - lo[0] + 1) * (size_t)(hi[1] - lo[1] + 1) * (size_t)(hi[2] - lo[2] + 1);
+    }
+    return pairs;
+}
+
+void wprep_grid_fill(const uint8_t* spheres, uint32_t ns, const wprep_grid* g, uint32_t* start, uint32_t* items,
+                     uint32_t* box) {
+    memset(start, 0, sizeof(uint32_t) * ((size_t)g->ncells + 1));
+    for (uint32_t i = 0; i < ns; i++) {         /* pass 1: counts (shifted by one for the prefix sum) */
+        int lo[3], hi[3];
+        sphere_cells(spheres + 96 * (size_t)i, g, lo, hi);
+        box[2 * i] = (uint32_t)lo[0] | (uint32_t)lo[1] << 10 | (uint32_t)lo[2] << 20;
+        box[2 * i + 1] = (uint32_t)hi[0] | (uint32_t)hi[1] << 10 | (uint32_t)hi[2] << 20;
+        for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++)
+                for (int x = lo[0]; x <= hi[0]; x++)
+                    start[((size_t)z * g->res[1] + y) * g->res[0] + x + 1]++;
+    }
+    for (uint32_t c = 0; c < g->ncells; c++) start[c + 1] += start[c];
+    uint32_t* cur = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)g->ncells);
+    memcpy(cur, start, sizeof(uint32_t) * (size_t)g->ncells);
+    for (uint32_t i = 0; i < ns; i++) {         /* pass 2: ascending sphere index inside every cell */
+        int lo[3], hi[3];
+        sphere_cells(spheres + 96 * (size_t)i, g, lo, hi);
+        for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++)
+                for (int x = lo[0]; x <= hi[0]; x++)
+                    items[cur[((size_t)z * g->res[1] + y) * g->res[0] + x]++] = i;
+    }
+    free(cur);
 }

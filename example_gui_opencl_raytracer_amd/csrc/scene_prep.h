@@ -11,6 +11,18 @@ size_t wprep_geom_f4(uint32_t ns, uint32_t np, uint32_t nl);
 /* geom: 4*wprep_geom_f4 floats; ptex: 8*np floats */
 void wprep_build(const uint8_t* spheres, uint32_t ns, const uint8_t* planes, uint32_t np,
                  const uint8_t* lights, uint32_t nl, float* geom, float* ptex);
+
+/* Uniform grid over the spheres (an acceleration structure for big scenes; it changes how many tests a ray
+ * makes, never their results).  wprep_grid_plan fills `g` (bounds, resolution) and returns the number of
+ * (cell, sphere) pairs; wprep_grid_fill then writes start[ncells+1], items[pairs], box[2*ns]. */
+typedef struct {
+    float gmin[3], inv[3], cell[3];
+    int32_t res[3];
+    uint32_t ncells;
+} wprep_grid;
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, wprep_grid* g);
+void wprep_grid_fill(const uint8_t* spheres, uint32_t ns, const wprep_grid* g, uint32_t* start, uint32_t* items,
+                     uint32_t* box);
 #ifdef __cplusplus
 }
 #endif

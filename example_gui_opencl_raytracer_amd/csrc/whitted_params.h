@@ -45,6 +45,14 @@ typedef struct {
     const uint8_t* planes_raw;  /* 96-B rplane array                                  */
     uint32_t ns, np, nl;
     uint32_t geom_f4;      /* number of float4 in geom                                */
+    /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
+     * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =
+     * sphere i's inclusive cell box, 10 bits per axis: lo = x0 | y0<<10 | z0<<20, hi likewise               */
+    const uint32_t* grid_start;
+    const uint32_t* grid_items;
+    const uint32_t* grid_box;
+    float grid_min[3], grid_inv[3], grid_cell[3];
+    int32_t grid_res[3];
     /* images: RGBA8 layer stacks */
     const uint32_t* tex; int32_t tex_w, tex_h, tex_layers;
     const uint32_t* sky; int32_t sky_w, sky_h;

@@ -88,6 +88,11 @@ void clw_ext_set_debug_rgb(cl_wrap* wrap, void* device_ptr_f32x3);
 void clw_ext_enable_counters(cl_wrap* wrap, int enable);
 void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
 
+/* Uniform grid over the spheres (default on; built for scenes with more than 256 spheres): rays test only the
+ * spheres registered in the cells they cross instead of all of them.  Same arithmetic per test, same nearest
+ * hit and same shadow factor as the reference's linear scan; 0 forces the linear scan. */
+void clw_ext_set_grid(cl_wrap* wrap, int on);
+
 /* Cost-sorted tile dispatch (default on): every 8x8 tile reports its cost, and the next frame serves each
  * XCD's tiles heaviest-first, so the expensive refraction tiles no longer end up in the tail of the launch.
  * Pure scheduling: the image is bit-identical either way. */

@@ -126,6 +126,41 @@ def test_many_spheres_wide_counts_and_global_geometry_path(R, oracle, tex, sky):
     check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
 
 
+GRID_CAMS = [dict(origin=(0.0, 6.0, -6.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0),        # above, looking across
+             dict(origin=(0.5, 0.3, 10.5), look=(1.0, 0.0, 0.0), fov=90.0, focal=1.0),          # INSIDE the grid, axis-parallel rays
+             dict(origin=(3.0, 25.0, 12.0), look=(0.0, -1.0, 0.001), fov=70.0, focal=1.0),      # straight down
+             dict(origin=(-30.0, 0.31, 12.0), look=(1.0, 0.0, 0.0), fov=40.0, focal=1.0)]       # grazing along the rows
+
+
+@pytest.mark.parametrize("cam", GRID_CAMS)
+@pytest.mark.parametrize("kind", ["opaque", "glass", "mixed"])
+def test_uniform_grid_equals_linear_scan(R, oracle, tex, sky, cam, kind):
+    """Scenes with > 256 spheres go through the uniform grid; the image must be bit-identical to the linear
+    scan (same arithmetic per test, same tie rule, transparent spheres counted once), and match the oracle."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sc = scene.sphere_grid_scene(24, 24)                       # 576 spheres, r 0.3, pitch 1
+    if kind != "opaque":
+        g = scene.glass()
+        sel = slice(None) if kind == "glass" else slice(0, None, 3)
+        for name in ("ambient", "diffuse", "specular", "shininess", "transperent", "dielectric", "n", "reflectivity"):
+            sc.spheres["material"][name][sel] = g[name]
+        sc.spheres["radius"][sel] = 0.55                       # overlapping neighbours: spheres span several cells
+        sc = scene.Scene(sc.spheres, sc.planes, sc.lights)
+    w, h, depth = 160, 100, 4
+    outs = {}
+    for strict in (True, False):
+        for grid in (1, 0):
+            r = Renderer(sc, tex, sky, w, h, depth=depth, strict=strict)
+            r.w.set_grid(grid)
+            r.look(**cam)
+            outs[(strict, grid)] = r.render()
+            r.release()
+        assert np.array_equal(outs[(strict, 1)], outs[(strict, 0)])
+    want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth)
+    check(outs[(True, 1)], want, 0.999)
+
+
 def test_lds_and_global_geometry_paths_agree_exactly(R, demo_scene, tex, sky):
     from example_gui_opencl_raytracer_amd.renderer import Renderer
     outs = []
