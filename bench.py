@@ -48,6 +48,22 @@ VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak fp32 vector
 FLOP = dict(sphere_test=34, plane_test=14, shadow_ray=40, light_shade=94, shaded_hit=73, sky=20, texel=25)
 
 
+def profiled_traffic():
+    """HBM bytes per trace launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_rocprof_summary.md: FETCH_SIZE and WRITE_SIZE, KiB per dispatch, separate passes).  The
+    guide's x2 FETCH_SIZE correction is for wide coalesced streams; this kernel's reads are 4-byte texel
+    gathers, so the raw counter is used (uncalibrated for that width)."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
+        txt = open(f).read()
+        fe, wr = re.search(r"^FETCH_SIZE,([0-9.]+)", txt, re.M), re.search(r"^WRITE_SIZE,([0-9.]+)", txt, re.M)
+        if fe and wr:
+            best = (int((float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f))
+    return best
+
+
 def cpu_baseline(sc, tex, sky):
     """The oracle (plain-C restatement, OpenMP over pixels) on this box's host cores: ONE full C2
     frame per run, 3 runs.  Returns (dict for the JSON line, oracle counters of the frame)."""
@@ -197,6 +213,7 @@ def main():
         # work-item + one 4-byte texel per texture / skybox fetch + the prepared geometry once
         bytes_launch = 4 * px_rank + 4 * (cnt["texel_fetches"] + cnt["sky_fetches"]) + 16 * (4 + 2 * 2 + 2 * 3)
         ach = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = profiled_traffic() if world == 1 else None
         line = {
             "metric": "Mrays/s (path segments + shadow rays) at 1920x1080 depth 4 per GPU",
             "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +228,8 @@ def main():
             "trace_kernel_ms": round(kernel_ms, 4),
             "lane_utilisation": round(float(tot[2].item() / max(tot[3].item(), 1.0)), 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic[0] if traffic else None,
+                         "algorithmic_bytes": bytes_launch, "traffic_source": traffic[1] if traffic else None,
                          "note": "algorithmic bytes/launch = 4 B x pixels + 4 B x texel fetches + geometry; the path is "
                                  "VALU-bound (723-byte scene), see roofline_valu"},
         }

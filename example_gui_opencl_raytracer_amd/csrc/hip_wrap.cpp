@@ -308,7 +308,8 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     for (uint32_t** q : {&I->d_grid_start, &I->d_grid_items, &I->d_grid_box}) { if (*q) { (void)hipFree(*q); *q = nullptr; } }
     I->grid_ok = false;
     if (ns > GRID_MIN_SPHERES) {
-        size_t pairs = wprep_grid_plan(hs, ns, &I->grid);
+        const char* dens = getenv("CLWRAP_GRID_DENSITY");   /* tuning knob: average spheres per cell */
+        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 0.25f, &I->grid);
         if (pairs <= GRID_MAX_PAIRS) {
             std::vector<uint32_t> st((size_t)I->grid.ncells + 1), it(pairs ? pairs : 1), bx(2 * (size_t)ns);
             wprep_grid_fill(hs, ns, &I->grid, st.data(), it.data(), bx.data());

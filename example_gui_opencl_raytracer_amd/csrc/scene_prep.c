@@ -95,7 +95,7 @@ static void sphere_cells(const uint8_t* s, const wprep_grid* g, int lo[3], int h
     }
 }
 
-size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, wprep_grid* g) {
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep_grid* g) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < ns; i++) {
         const uint8_t* s = spheres + 96 * (size_t)i;
@@ -115,7 +115,7 @@ size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, wprep_grid* g) {
         vol *= ext[a];
     }
     /* about one sphere per cell, cubic cells, 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
-    float side = cbrtf(vol / (float)(ns ? ns : 1));
+    float side = cbrtf(vol * density / (float)(ns ? ns : 1));   /* `density` spheres per cell on average */
     uint64_t total = 1;
     for (int a = 0; a < 3; a++) {
         int n = (int)(ext[a] / side + 0.5f);

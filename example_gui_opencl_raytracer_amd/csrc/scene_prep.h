@@ -20,7 +20,7 @@ typedef struct {
     int32_t res[3];
     uint32_t ncells;
 } wprep_grid;
-size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, wprep_grid* g);
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep_grid* g);
 void wprep_grid_fill(const uint8_t* spheres, uint32_t ns, const wprep_grid* g, uint32_t* start, uint32_t* items,
                      uint32_t* box);
 #ifdef __cplusplus
