@@ -101,14 +101,15 @@ def main():
     ap.add_argument("--dump-png", default=None, help="rank 0 writes the assembled frame here")
     args = ap.parse_args()
 
-    rank, world, local_rank = D.init_process_group("gloo" if args.rehearse else None)
-    if args.rehearse:
-        local_rank = 0          # every rank on cuda:0, gathers staged through the CPU (no RCCL on one GPU)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    _, _, local_rank = D.env_rank_world()
+    if args.rehearse:
+        local_rank = 0          # every rank on cuda:0, gathers staged through the CPU (no RCCL on one GPU)
+    torch.cuda.set_device(local_rank)          # before the process group: RCCL binds to the current device
+    rank, world, _ = D.init_process_group("gloo" if args.rehearse else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local_rank)
 
     sc = scene.render_map_scene()

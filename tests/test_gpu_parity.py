@@ -277,3 +277,68 @@ def test_large_frame_is_deterministic_and_tile_order_free(R, tex, sky):
         r.release()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert len(np.unique(outs[0])) > 1000
+
+
+# ------------------------------------------------------------ the other BASELINE.json configurations at FULL size
+def test_full_size_c3_glass_field_against_the_oracle(R, oracle, tex):
+    """Config C3: 4096x4096, depth 8, 64 dielectric spheres.  493 M rays: the oracle needs the GPU box's host cores."""
+    from example_gui_opencl_raytracer_amd import scene, textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sky4k = textures.skybox_cross(4096)
+    sc = scene.dielectric_field_scene(8)
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    w = h = 4096
+    want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky4k, 8)
+    assert 29.0 < cnt.rays / (w * h) < 30.0
+    r = Renderer(sc, tex, sky4k, w, h, depth=8, strict=True)
+    r.look(**cam)
+    check(r.render(), want, 0.9995)
+    r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.release()
+    assert c["segments"] + c["shadow_rays"] == cnt.rays
+    r = Renderer(sc, tex, sky4k, w, h, depth=8, strict=False)
+    r.look(**cam)
+    check(r.render(), want, 0.99, 0.995)
+    r.release()
+
+
+def test_full_size_c4_ten_thousand_spheres_against_the_oracle(R, oracle, tex):
+    """Config C4: 100x100 opaque spheres, 1920x1080, depth 4 -- the uniform-grid path against the oracle's
+    brute-force scan (2.7e11 sphere tests on the host cores)."""
+    from example_gui_opencl_raytracer_amd import scene, textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sky4k = textures.skybox_cross(4096)
+    sc = scene.sphere_grid_scene(100, 100)
+    cam = dict(origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
+    w, h = 1920, 1080
+    want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky4k, 4)
+    r = Renderer(sc, tex, sky4k, w, h, depth=4, strict=True)
+    r.look(**cam)
+    check(r.render(), want, 0.9995)
+    r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.release()
+    assert c["segments"] + c["shadow_rays"] == cnt.rays
+
+
+def test_full_size_c5_strips_equal_the_single_gpu_frame(R, oracle, demo_scene, tex):
+    """Config C5: 8192x8192, depth 4, eight row strips.  Size-independent property at the full size: every strip is
+    bit-identical to its rows of the one-GPU frame; two strips are also checked against the oracle."""
+    from example_gui_opencl_raytracer_amd import textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer, strip_rows
+    sky4k = textures.skybox_cross(4096)
+    w = h = 8192
+    full = Renderer(demo_scene, tex, sky4k, w, h, depth=4, strict=True)
+    full.look(**CAM)
+    want = full.render()
+    full.release()
+    import zlib
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    for rank in range(8):
+        r0, rows = strip_rows(h, 8, rank)
+        assert rows == 1024
+        s = Renderer(demo_scene, tex, sky4k, w, h, depth=4, strict=True, first_row=r0, rows=rows)
+        s.look(**CAM)
+        got = s.render()
+        s.release()
+        assert zlib.crc32(got.tobytes()) == zlib.crc32(want[r0 * w:(r0 + rows) * w].tobytes())
+        if rank in (3, 5):
+            ref, _, _ = oracle.render(cam, demo_scene, tex, sky4k, 4, id_begin=r0 * w, id_end=(r0 + 64) * w)
+            check(got[:64 * w], ref, 0.9995)
