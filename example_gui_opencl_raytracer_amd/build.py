@@ -21,12 +21,13 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CC = os.environ.get("CC") or "gcc"
 
-DEVICE_DEPS = ["whitted_trace.inc", "whitted_launch.inc", "whitted_params.h"]
+DEVICE_DEPS = ["whitted_trace.inc", "whitted_hit.inc", "whitted_bounce.inc", "whitted_pop.inc", "whitted_launch.inc", "whitted_params.h"]
 UNITS = [
     # (source, compiler, flags, extra deps)
+    # -ffp-contract=off on BOTH builds: the fast build fuses where its source says fma, nowhere else.
     # -fno-slp-vectorize: v_pk_{mul,add,fma}_f32 buy no fp32 throughput on gfx950 (plain v_fma_f32 already
     # runs at the vector peak) but cost aligned register pairs: 126 -> 96 VGPRs and -15 % kernel time here.
-    ("whitted_fast.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-fno-slp-vectorize"], DEVICE_DEPS),
+    ("whitted_fast.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-ffp-contract=off"], DEVICE_DEPS),
     ("whitted_strict.hip", "hip", ["-O3", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-ffp-contract=off"], DEVICE_DEPS),
     ("hip_wrap.cpp", "hip", ["-O2", "-std=c++17", "-Wall"],
      ["whitted_params.h", "scene_prep.h", "png_codec.h", "../../include/opencl_wrap.h", "../../include/hip_wrap_ext.h"]),

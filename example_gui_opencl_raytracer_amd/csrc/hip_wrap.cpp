@@ -372,6 +372,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
     P.out = (uint32_t*)out->dptr;
     P.out_rgb = I->debug_rgb;
+    P.coop_max = (I->variant & 16) ? 0u : 10u;
 
     int flags = 0;
     const bool fused = I->fuse && rays->gen_valid;
@@ -664,6 +665,15 @@ void clw_ext_sync(cl_wrap* wrap) { Impl* I = impl_of(wrap); use_device(I); finis
 void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {
     Impl* I = impl_of(wrap);
     I->stream = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
+}
+uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    finish(I);
+    if (!I->d_tile_cost) return 0;
+    uint32_t n = ((I->sched_rows + 7) / 8) * ((I->sched_w + 7) / 8);
+    if (out && capacity >= n) HIP_OK(hipMemcpy(out, I->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    return n;
 }
 void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 : 0; }
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; I->sched_valid = false; }

@@ -37,6 +37,7 @@ typedef struct {
      * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    uint32_t coop_max;     /* <= this many shading lanes -> their shadow rays are spread over the wave (0 = never) */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */
     const float* geom;     /* float4 stream, layout above                             */

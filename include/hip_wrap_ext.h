@@ -98,6 +98,10 @@ void clw_ext_set_grid(cl_wrap* wrap, int on);
  * Pure scheduling: the image is bit-identical either way. */
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on);
 
+/* The per-tile cost table of the last tiled launch (row-major 8x8 tiles; cost = loop iterations of the tile's
+ * most expensive pixel, +3 per shaded hit).  Returns the number of tiles; copies them if `capacity` suffices. */
+uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity);
+
 /* Kernel build variant for A/B measurements; 0 = default. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
