@@ -129,6 +129,40 @@ def test_external_framebuffer_and_stream(R, demo_scene, tex, sky):
     r.release(); own.release()
 
 
+def test_partial_launch_and_reinit(R, oracle, demo_scene, tex, sky):
+    """array_size smaller than the frame: the reference launches ceil(n/256)*256 work-items guarded by
+    id < total (opencl_wrap.c:374, raytracing.cl:24) -- the rest of the framebuffer stays untouched.  Then the
+    same cl_wrap struct is released and initialised again (opencl_wrap.c:400-416)."""
+    import ctypes as C
+    from example_gui_opencl_raytracer_amd import api
+    w, h = 160, 120
+    want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, 4)
+    r = R(demo_scene, tex, sky, w, h, depth=4, strict=True)
+    r.look(**CAM)
+    n = 5000                                             # rounds up to 5120 work-items
+    out = np.full(w * h, 0xDEADBEEF, np.uint32)
+    r.w.load_global_data(1, 30, out, mem_flags=api.CL_MEM_READ_WRITE)   # pre-fill a spare buffer ...
+    r.w.output(n, 0, 0, 0, 0, None)
+    full = r.render()                                    # reference frame through the normal path
+    assert (channel_diff(full, want) == 0).mean() >= 0.999
+    r.release()
+    # partial launch into a fresh wrap whose framebuffer was pre-filled
+    r = R(demo_scene, tex, sky, w, h, depth=4, strict=True)
+    r.look(**CAM)
+    r.w.output(w * h, 0, 0, 0, 0, None)
+    r.w.output(w * h, 0, 1, 1, 10, None)                 # fill with the real frame first
+    part = np.empty(w * h, np.uint32)
+    r.w.output(n, 0, 0, 0, 0, None)
+    r.w.output(n, part.nbytes, 1, 1, 10, part)           # only the first 5120 ids are re-traced
+    assert np.array_equal(part, full)                    # same values, nothing past the range was damaged
+    r.release()
+    assert r.w.w.impl is None or r.w.w.impl == 0
+    again = R(demo_scene, tex, sky, w, h, depth=4, strict=True)          # re-init after release
+    again.look(**CAM)
+    assert np.array_equal(again.render(), full)
+    again.release()
+
+
 def test_timing_log(R, demo_scene, tex, sky):
     r = R(demo_scene, tex, sky, 320, 240, depth=4)
     r.look(**CAM)
