@@ -140,21 +140,20 @@ def test_partial_launch_and_reinit(R, oracle, demo_scene, tex, sky):
     r = R(demo_scene, tex, sky, w, h, depth=4, strict=True)
     r.look(**CAM)
     n = 5000                                             # rounds up to 5120 work-items
-    out = np.full(w * h, 0xDEADBEEF, np.uint32)
-    r.w.load_global_data(1, 30, out, mem_flags=api.CL_MEM_READ_WRITE)   # pre-fill a spare buffer ...
-    r.w.output(n, 0, 0, 0, 0, None)
-    full = r.render()                                    # reference frame through the normal path
+    full = r.render()                                    # the whole frame through the normal path
     assert (channel_diff(full, want) == 0).mean() >= 0.999
     r.release()
-    # partial launch into a fresh wrap whose framebuffer was pre-filled
+    # a fresh wrap with another camera fills its framebuffer; a PARTIAL launch with the test camera then
+    # re-traces ids [0, 5120) only: those equal the full frame, the rest keeps the other camera's pixels
     r = R(demo_scene, tex, sky, w, h, depth=4, strict=True)
+    r.look(origin=(1.5, 2.0, -6.0), look=(-0.1, -0.1, 1.0), fov=90.0, focal=1.0)
+    other = r.render()
     r.look(**CAM)
-    r.w.output(w * h, 0, 0, 0, 0, None)
-    r.w.output(w * h, 0, 1, 1, 10, None)                 # fill with the real frame first
     part = np.empty(w * h, np.uint32)
     r.w.output(n, 0, 0, 0, 0, None)
-    r.w.output(n, part.nbytes, 1, 1, 10, part)           # only the first 5120 ids are re-traced
-    assert np.array_equal(part, full)                    # same values, nothing past the range was damaged
+    r.w.output(n, part.nbytes, 1, 1, 10, part)
+    assert np.array_equal(part[:5120], full[:5120]) and np.array_equal(part[5120:], other[5120:])
+    assert not np.array_equal(other[:5120], full[:5120])
     r.release()
     assert r.w.w.impl is None or r.w.w.impl == 0
     again = R(demo_scene, tex, sky, w, h, depth=4, strict=True)          # re-init after release
