@@ -217,6 +217,13 @@ def test_launch_with_missing_arguments_exits():
     assert p.returncode == 1 and "ERROR:\tCouldn't run the kernel" in p.stdout
 
 
+def test_argument_id_limit_exits():
+    p = _run("w = api.ClWrap()\nw.load_global_data(1, 32, np.zeros(4, np.uint8))")      # __MAX_BUFFERS = 32 (opencl_wrap.h:7)
+    assert p.returncode == 1 and "ERROR:\tWrong kernel ID given" in p.stdout               # the reference's wording (opencl_wrap.c:144)
+    p = _run("w = api.ClWrap()\nw.output(64, 0, 7, 0, 0, None)")                          # kernel id out of range
+    assert p.returncode == 1 and "ERROR:" in p.stdout
+
+
 def test_depth_out_of_range_exits():
     p = _run("w = api.ClWrap()\nw.set_depth(33)")
     assert p.returncode == 1 and "ERROR:" in p.stdout

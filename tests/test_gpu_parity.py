@@ -220,6 +220,51 @@ def test_empty_primitive_lists(R, oracle, demo_scene, tex, sky):
         assert (channel_diff(got, want) == 0).mean() >= 0.999, name
 
 
+@pytest.mark.parametrize("nl", [1, 2, 4, 7])
+def test_light_counts_around_the_chunk_size(R, oracle, demo_scene, tex, sky, nl):
+    """Lights are shaded three at a time (six shadow rays together): counts that are not multiples of three
+    exercise the partial chunk; the RNG stream must still be drawn light by light in the reference's order."""
+    from example_gui_opencl_raytracer_amd.scene import Scene, LIGHT
+    lights = np.zeros(nl, LIGHT)
+    base = demo_scene.lights
+    for i in range(nl):
+        lights[i] = base[i % 3]
+        lights[i]["origin"] = base[i % 3]["origin"] + np.float32(0.7 * (i // 3)) * np.array([1.0, 0.3, -0.5], np.float32)
+        lights[i]["intensity"] = base[i % 3]["intensity"] / np.float32(1 + i // 3)
+    sc = Scene(demo_scene.spheres, demo_scene.planes, lights)
+    w, h = 128, 96
+    want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 6)
+    assert cnt.shadow_rays == 2 * nl * cnt.shaded_hits
+    check(gpu_frame(R, sc, tex, sky, w, h, 6, True), want, 0.999)       # depth 6: deep build, sparse-tail loop too
+    check(gpu_frame(R, sc, tex, sky, w, h, 4, True), oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 4)[0], 0.999)
+
+
+def test_maximum_one_byte_counts(R, oracle, tex, sky):
+    """255 spheres, 255 planes... would be absurdly slow on the oracle; 255 spheres + 3 planes + 255 lights is the
+    largest scene the reference's one-byte counts can express in the dimensions that matter (raytracing.cl:17)."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.scene import Scene, LIGHT, PLANE
+    big = scene.sphere_grid_scene(17, 15)                       # 255 spheres
+    assert len(big.spheres) == 255
+    planes = np.zeros(3, PLANE)
+    planes[0] = big.planes[0]
+    planes[1] = scene.render_map_scene().planes[1]
+    planes[2] = scene.render_map_scene().planes[1]
+    planes[2]["normal"] = (1.0, 0.0, 0.0); planes[2]["point_in_plane"] = (-12.0, 0.0, 0.0)
+    lights = np.zeros(255, LIGHT)
+    rng = np.random.default_rng(5)
+    lights["origin"] = rng.uniform([-8, 1.5, 0], [8, 6, 14], (255, 3)).astype(np.float32)
+    lights["radius"] = 0.1
+    lights["intensity"] = 0.6
+    lights["rgb"] = rng.uniform(0.2, 1.0, (255, 3)).astype(np.float32)
+    sc = Scene(big.spheres, planes, lights)
+    cam = dict(origin=(0.0, 6.0, -6.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
+    w, h = 48, 32
+    want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, 2)
+    assert cnt.shadow_rays == 510 * cnt.shaded_hits
+    check(gpu_frame(R, sc, tex, sky, w, h, 2, True, cam=cam, wide_counts=False), want, 0.995)
+
+
 def test_count_width_is_irrelevant(R, demo_scene, tex, sky):
     a = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=False)     # uchar counts (reference)
     b = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=True)      # 4-byte counts (extension)
