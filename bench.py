@@ -107,6 +107,7 @@ def main():
     if args.rehearse:
         local_rank = 0          # every rank on cuda:0, gathers staged through the CPU (no RCCL on one GPU)
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds to the current device
+    os.environ["CLWRAP_DEVICE"] = str(local_rank)   # the shim binds to the same GPU explicitly
     rank, world, _ = D.init_process_group("gloo" if args.rehearse else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
