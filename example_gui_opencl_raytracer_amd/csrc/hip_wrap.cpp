@@ -39,7 +39,8 @@ constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: C
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
 constexpr int LDS_LEVELS = 3;
-constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes with more spheres than fit one-byte counts get the uniform grid */
+constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes beyond the reference's one-byte counts get the uniform grid (at 64 spheres it only
+                                                wins when the cells happen to align with the spheres: 9.2-15 ms vs 10.9 ms linear) */
 constexpr size_t GRID_MAX_PAIRS = (size_t)1 << 27;
 
 [[noreturn]] void die(const char* fmt, ...) {
@@ -287,6 +288,11 @@ const uint8_t* host_view(Impl* I, Buffer* b, size_t need, std::vector<uint8_t>& 
     return tmp.data();
 }
 
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
 void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buffer* l, uint32_t nl) {
     if (I->d_geom && I->prep_s == s && I->prep_p == p && I->prep_l == l && I->prep_ns == ns &&
         I->prep_np == np && I->prep_nl == nl)
@@ -307,9 +313,9 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     /* uniform grid over the spheres for big scenes */
     for (uint32_t** q : {&I->d_grid_start, &I->d_grid_items, &I->d_grid_box}) { if (*q) { (void)hipFree(*q); *q = nullptr; } }
     I->grid_ok = false;
-    if (ns > GRID_MIN_SPHERES) {
+    if (ns > (uint32_t)env_int("CLWRAP_GRID_MIN", (int)GRID_MIN_SPHERES)) {   /* CLWRAP_GRID_MIN: tuning knob */
         const char* dens = getenv("CLWRAP_GRID_DENSITY");   /* tuning knob: average spheres per cell */
-        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 0.25f, &I->grid);
+        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 1.4f, &I->grid);
         if (pairs <= GRID_MAX_PAIRS) {
             std::vector<uint32_t> st((size_t)I->grid.ncells + 1), it(pairs ? pairs : 1), bx(2 * (size_t)ns);
             wprep_grid_fill(hs, ns, &I->grid, st.data(), it.data(), bx.data());
@@ -468,10 +474,6 @@ void run_raygen(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     }
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
 
 } /* namespace */
 

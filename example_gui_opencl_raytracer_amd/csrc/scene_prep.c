@@ -114,8 +114,16 @@ size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep
         mn[a] -= pad; mx[a] += pad; ext[a] = mx[a] - mn[a];
         vol *= ext[a];
     }
-    /* about one sphere per cell, cubic cells, 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
-    float side = cbrtf(vol * density / (float)(ns ? ns : 1));   /* `density` spheres per cell on average */
+    /* cubic cells about one mean sphere diameter wide (finer cells make every sphere span several of them, coarser
+     * ones put several spheres in a cell), kept between 1/8 and 4 spheres per cell on average; `density` scales
+     * the side (tuning knob; the shim passes 1.4); 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
+    double diam = 0.0;
+    for (uint32_t i = 0; i < ns; i++) diam += 2.0 * ldf(spheres + 96 * (size_t)i, 16);
+    diam /= (double)(ns ? ns : 1);
+    float side_lo = cbrtf(vol * 0.125f / (float)(ns ? ns : 1)), side_hi = cbrtf(vol * 4.0f / (float)(ns ? ns : 1));
+    float side = (float)diam * density;
+    if (!(side > side_lo)) side = side_lo;
+    if (side > side_hi) side = side_hi;
     uint64_t total = 1;
     for (int a = 0; a < 3; a++) {
         int n = (int)(ext[a] / side + 0.5f);
