@@ -387,3 +387,20 @@ def test_full_size_c5_strips_equal_the_single_gpu_frame(R, oracle, demo_scene, t
         if rank in (3, 5):
             ref, _, _ = oracle.render(cam, demo_scene, tex, sky4k, 4, id_begin=r0 * w, id_end=(r0 + 64) * w)
             check(got[:64 * w], ref, 0.9995)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_against_the_oracle(R, oracle, tex, sky, seed):
+    """Fuzz: the scenes of tests/fuzz_scenes.py (0-8 spheres, 0-3 planes, 0-4 lights, any material, depth 1-15)."""
+    from fuzz_scenes import random_scene
+    sc, cam, depth = random_scene(seed)
+    w, h = 72, 48
+    want, rgb, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth, want_rgb=True)
+    if cnt.int_cast_oor or cnt.oob_reads:
+        pytest.skip("scene hits an undefined float->int conversion / image read in the reference")
+    got = gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam)
+    d = channel_diff(got, want)
+    assert (d == 0).mean() >= 0.995, f"seed {seed}: strict build {(d == 0).mean():.4f} exact"
+    fast = gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam)
+    df = channel_diff(fast, want)
+    assert (df <= 1).mean() >= 0.97, f"seed {seed}: fast build {(df <= 1).mean():.4f} within 1 LSB"

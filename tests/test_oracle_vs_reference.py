@@ -81,3 +81,17 @@ def test_against_the_references_committed_render(oracle, demo_scene):
     print(f"vs out/scene.png: exact {exact:.4f}, <=1 LSB {le1:.4f}, max {d.max()}, mean {d.mean():.4f}")
     assert exact > 0.85 and le1 > 0.92 and d.mean() < 1.0
     assert cnt.oob_reads == 0 and cnt.int_cast_oor == 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_bit_exact(oracle, reference, tex, sky, seed):
+    """Fuzz: random primitive counts (including none), random materials / textures / cameras / depths."""
+    from fuzz_scenes import random_scene
+    sc, cam, depth = random_scene(seed)
+    c = oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, 72, 48)
+    want, _ = reference.render(c, sc, tex, sky, depth)
+    got, _, cnt = oracle.render(c, sc, tex, sky, depth)
+    # the x86 build of the reference converts out-of-range floats to INT_MIN where the oracle saturates like AMD
+    # hardware; only compare scenes in which no such conversion happened (the counters tell)
+    if cnt.int_cast_oor == 0 and cnt.oob_reads == 0:
+        assert np.array_equal(got, want), f"seed {seed}: {(got != want).sum()} pixels differ"
