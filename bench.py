@@ -15,8 +15,8 @@ resident in HBM and the framebuffer left in HBM.
 N > 1 (weak scaling): every GPU keeps a 1920x1080 share of ONE 1920 x (1080*N) frame -- rank r
 owns every N-th 8-row band (interleaved so the shares cost the same) with GLOBAL work-item ids,
 so the assembled frame is bit-identical to a single-GPU render.  No data-path collective while
-tracing; each step ends with one gather of the bands to rank 0 over RCCL/xGMI, double-buffered so
-it overlaps the next frame's trace.
+tracing; each step ends with one gather of the bands (packed to RGB888) to rank 0 over RCCL/xGMI on
+a side stream, double-buffered so it overlaps the next frame's trace.
 
 rays = path segments + shadow rays, counted by the counting build of the kernel
 outside the timed region.  rank 0 prints ONE JSON line.
@@ -98,6 +98,8 @@ def main():
                     help="experiment: each frame slot launches on its own stream, so consecutive frames overlap")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a ONE-GPU box: gloo backend, all ranks on cuda:0 (checks the sharded path, not RCCL)")
+    ap.add_argument("--rehearse-device-tensors", action="store_true",
+                    help="with --rehearse: hand the GPU tensors to gloo directly (exercises the side-stream packing path)")
     ap.add_argument("--dump-png", default=None, help="rank 0 writes the assembled frame here")
     args = ap.parse_args()
 
@@ -133,16 +135,16 @@ def main():
         r.look(**pkg.CAMERA_RAYPNG)
         r.w.set_async(True)
         rr.append(r)
-    gat = D.BandGatherer(W, H, rank, world, dev, staged_on_cpu=args.rehearse)
+    gat = D.BandGatherer(W, H, rank, world, dev, staged_on_cpu=args.rehearse and not args.rehearse_device_tensors)
 
     def step(k):
         s = k & 1
-        gat.wait(s)                                # frame k-2 has left this slot
+        gat.before_render(s)                       # frame k-2's pixels have been packed for their gather
         rr[s].render(readback=False)               # raygen latch + trace launch (async, torch's stream)
         if world > 1:
             if args.rehearse:
                 torch.cuda.current_stream().synchronize()
-            gat.gather_async(s, fbs[s])
+            gat.submit(s, fbs[s])                  # pack to RGB888 + gather on the side stream
 
     def drain():
         gat.drain()

@@ -78,8 +78,8 @@ def _band_worker(rank, world, port, out_path):
                             for b in range(rank, h // 8, world)])
     gat = D.BandGatherer(w, h, rank, world, torch.device("cpu"))
     for frame in range(3):                          # both slots, and reuse of slot 0
-        gat.wait(frame & 1)
-        gat.gather_async(frame & 1, torch.from_numpy(share.view(np.int32)))
+        gat.before_render(frame & 1)
+        gat.submit(frame & 1, torch.from_numpy(share.view(np.int32)))
     gat.drain()
     dist.barrier()
     if rank == 0:
