@@ -64,6 +64,18 @@ def profiled_traffic():
     return best
 
 
+def profiled_valu_instructions():
+    """SQ_INSTS_VALU per trace launch (wave-level VALU instructions) from the committed PMC pass."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
+        m = re.search(r"^SQ_INSTS_VALU,([0-9.]+)", open(f).read(), re.M)
+        if m:
+            best = (float(m.group(1)), os.path.basename(f))
+    return best
+
+
 def cpu_baseline(sc, tex, sky):
     """The oracle (plain-C restatement, OpenMP over pixels) on this box's host cores: ONE full C2
     frame per run, 3 runs.  Returns (dict for the JSON line, oracle counters of the frame)."""
@@ -237,6 +249,14 @@ def main():
                          "note": "algorithmic bytes/launch = 4 B x pixels + 4 B x texel fetches + geometry; the path is "
                                  "VALU-bound (723-byte scene), see roofline_valu"},
         }
+        vi = profiled_valu_instructions() if world == 1 else None
+        if vi:
+            # plain wave64 VALU instructions issue at 1.04 ns per SIMD (tools/ubench/valu_rates.hip, MI355X, 1 024 SIMDs)
+            peak = 1024 / 1.04e-9 / 1e12
+            got = vi[0] / (kernel_ms * 1e-3) / 1e12
+            line["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(got, 4), "peak": round(peak, 4),
+                                           "unit": "T wave-instructions/s", "frac": round(got / peak, 4),
+                                           "instructions_per_launch": int(vi[0]), "source": vi[1]}
         if world == 1 and not args.no_cpu_baseline:
             base, oc = cpu_baseline(sc, tex, sky)
             line["cpu_baseline"] = base
