@@ -224,6 +224,27 @@ def test_argument_id_limit_exits():
     assert p.returncode == 1 and "ERROR:" in p.stdout
 
 
+def test_environment_knobs(oracle, demo_scene, tex, sky):
+    """CLWRAP_DEPTH / CLWRAP_STRICT / CLWRAP_FUSE are read by cl_wrap_init: an unchanged driver is configured by
+    the environment alone (the reference bakes MAX_DEPTH into the kernel source, raytracing.cl:9)."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import example_gui_opencl_raytracer_amd as pkg\n"
+        "from example_gui_opencl_raytracer_amd import api, scene, textures\n"
+        "from example_gui_opencl_raytracer_amd.renderer import Renderer\n"
+        "w = api.ClWrap(); print('depth', w.get_depth()); w.release()\n"
+        "r = Renderer.__new__(Renderer)\n" % ROOT)
+    env = dict(os.environ, CLWRAP_DEPTH="3", CLWRAP_STRICT="1", CLWRAP_FUSE="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "depth 3" in p.stdout, p.stdout + p.stderr
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, CLWRAP_DEPTH="99"), timeout=300)
+    assert p.returncode == 1 and "ERROR:" in p.stdout
+    p = _run("import ctypes as C\nL = api.load_library(); w = api.cl_wrap()\n"
+             "L.cl_wrap_init(C.byref(w), C.c_uint64(1 << 1), C.c_char_p(b'a.cl'), C.c_char_p(b'raygen'), C.c_char_p(None))")   # CL_DEVICE_TYPE_CPU
+    assert p.returncode == 1 and "ERROR:\tCannot find a device of the given type" in p.stdout      # opencl_wrap.c:31-34
+
+
 def test_depth_out_of_range_exits():
     p = _run("w = api.ClWrap()\nw.set_depth(33)")
     assert p.returncode == 1 and "ERROR:" in p.stdout
