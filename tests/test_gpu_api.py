@@ -110,6 +110,32 @@ def test_interleaved_bands_are_bit_identical_to_the_full_frame(R, demo_scene, te
             s.release()
 
 
+def test_bands_with_the_grid_the_deep_build_and_the_sorted_dispatch(R, tex, sky):
+    """Everything at once: a 400-sphere scene (uniform grid), depth 6 (deep build with the sparse-tail loop),
+    interleaved bands, and a second frame per renderer (cost-sorted dispatch order) -- still the single-GPU bits."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.sphere_grid_scene(20, 20)
+    g = scene.glass()
+    for name in ("ambient", "diffuse", "specular", "shininess", "transperent", "dielectric", "n", "reflectivity"):
+        sc.spheres["material"][name][::2] = g[name]
+    sc = scene.Scene(sc.spheres, sc.planes, sc.lights)
+    cam = dict(origin=(0.0, 5.0, -5.0), look=(0.0, -0.5, 1.0), fov=90.0, focal=1.0)
+    w, h, world = 200, 96, 3
+    for strict in (True, False):
+        full = R(sc, tex, sky, w, h, depth=6, strict=strict)
+        full.look(**cam)
+        want = full.render()
+        assert np.array_equal(full.render(), want)            # second frame: sorted order
+        full.release()
+        want = want.reshape(h // 8, 8 * w)
+        for rank in range(world):
+            s = R(sc, tex, sky, w, h, depth=6, strict=strict, bands=(world, rank))
+            s.look(**cam)
+            for _ in range(2):
+                assert np.array_equal(s.render().reshape(-1, 8 * w), want[rank::world])
+            s.release()
+
+
 def test_external_framebuffer_and_stream(R, demo_scene, tex, sky):
     """bench.py's plumbing: torch owns the framebuffer and the stream, the shim renders into it."""
     import torch
