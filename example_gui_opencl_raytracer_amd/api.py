@@ -34,7 +34,7 @@ SYMBOLS = [
     "clw_ext_set_id_offset", "clw_ext_set_row_bands", "clw_ext_set_async", "clw_ext_sync", "clw_ext_set_stream",
     "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
-    "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_set_grid", "clw_ext_set_variant",
+    "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_unit", "clw_ext_set_grid", "clw_ext_set_variant",
     "clw_host_perspective", "clw_host_write_png", "clw_host_write_png_rgba", "clw_host_read_png",
     "clw_host_free", "clw_ext_version",
 ]
@@ -92,6 +92,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.clw_ext_device_ptr.argtypes = [W, u32, u32]
     L.clw_ext_device_ptr.restype = vp
     L.clw_ext_set_debug_rgb.argtypes = [W, vp]
+    L.clw_ext_unit.argtypes = [W, C.c_int, vp, u32, vp, u32, u32, u32]
     L.clw_ext_read_tile_costs.argtypes = [W, vp, u32]
     L.clw_ext_read_tile_costs.restype = u32
     L.clw_ext_read_counters.argtypes = [W, C.POINTER(C.c_uint64 * 8)]
@@ -217,6 +218,13 @@ class ClWrap:
     def set_async(self, a): self.L.clw_ext_set_async(C.byref(self.w), int(a))
     def sync(self): self.L.clw_ext_sync(C.byref(self.w))
     def set_stream(self, s): self.L.clw_ext_set_stream(C.byref(self.w), C.c_void_p(s))
+    def unit(self, op: int, rows: np.ndarray, out_cols: int, aux: int = 0) -> np.ndarray:
+        """Run one device helper (see clw_ext_unit) over float32 rows -> float32 [n, out_cols]."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        out = np.zeros((rows.shape[0], out_cols), np.float32)
+        self.L.clw_ext_unit(C.byref(self.w), op, _ptr(rows), rows.shape[1], _ptr(out), out_cols, rows.shape[0], aux)
+        return out
+
     def read_tile_costs(self) -> np.ndarray:
         n = self.L.clw_ext_read_tile_costs(C.byref(self.w), None, 0)
         out = np.zeros(n, np.uint32)

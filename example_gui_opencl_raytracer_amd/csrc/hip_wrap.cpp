@@ -30,6 +30,8 @@ extern "C" hipError_t wt_fast_launch_trace(const whitted_params*, int, unsigned,
 extern "C" hipError_t wt_fast_launch_raygen(const raygen_params*, hipStream_t);
 extern "C" hipError_t wt_strict_launch_trace(const whitted_params*, int, unsigned, size_t, hipStream_t);
 extern "C" hipError_t wt_strict_launch_raygen(const raygen_params*, hipStream_t);
+extern "C" hipError_t wt_fast_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
+extern "C" hipError_t wt_strict_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, hipStream_t);
 
 namespace {
@@ -667,6 +669,24 @@ void clw_ext_sync(cl_wrap* wrap) { Impl* I = impl_of(wrap); use_device(I); finis
 void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream) {
     Impl* I = impl_of(wrap);
     I->stream = hip_stream ? (hipStream_t)hip_stream : I->own_stream;
+}
+void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, float* out, uint32_t stride_out, uint32_t n,
+                  uint32_t aux) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    if (n == 0) return;
+    float *din = nullptr, *dout = nullptr;
+    HIP_OK(hipMalloc((void**)&din, (size_t)n * stride_in * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMalloc((void**)&dout, (size_t)n * stride_out * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMemcpy(din, in, (size_t)n * stride_in * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    HIP_OK(hipMemset(dout, 0, (size_t)n * stride_out * 4), "Couldn't allocate device memory");
+    HIP_OK(hipDeviceSynchronize(), "The device kernel failed");
+    hipError_t e = I->strict ? wt_strict_launch_unit(op, din, dout, n, stride_in, stride_out, aux, I->stream)
+                             : wt_fast_launch_unit(op, din, dout, n, stride_in, stride_out, aux, I->stream);
+    if (e != hipSuccess) die("Couldn't run the kernel");
+    finish(I);
+    HIP_OK(hipMemcpy(out, dout, (size_t)n * stride_out * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    (void)hipFree(din); (void)hipFree(dout);
 }
 uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity) {
     Impl* I = impl_of(wrap);

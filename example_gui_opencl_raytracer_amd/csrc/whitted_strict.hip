@@ -12,4 +12,5 @@
 #define WT_LAUNCH_TRACE wt_strict_launch_trace
 #define WT_LAUNCH_RAYGEN wt_strict_launch_raygen
 #define WT_LAUNCH_SCHED wt_strict_launch_sched
+#define WT_LAUNCH_UNIT wt_strict_launch_unit
 #include "whitted_launch.inc"

@@ -102,6 +102,15 @@ void clw_ext_set_tile_sched(cl_wrap* wrap, int on);
  * most expensive pixel, +3 per shaded hit).  Returns the number of tiles; copies them if `capacity` suffices. */
 uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity);
 
+/* Runs ONE device helper of the trace kernel over `n` input rows (host arrays; rows of `stride_in` / `stride_out`
+ * floats) in the current arithmetic mode -- function-level parity tests against the reference's own functions.
+ * op: 0 intersect_sphere {o,d,c,r -> hit,t}  1 intersect_plane {o,d,n,p0 -> hit,t}  2 reflect {i,n -> r}
+ *     3 refract {n1,n2,i,n -> ok,r}  4 compute_schlick {n1,n2,i,n -> f}  5 map_to_cube {dir -> u,v bits; aux = face}
+ *     6 xorshift32 {state bits -> state bits, value}  7 euclidean_modulo {a,b bits -> m bits}
+ *     8 sin/cos {x -> s,c}  9 pow {x,y -> x^y}  10 normalize {v -> unit, length}. */
+void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, float* out, uint32_t stride_out,
+                  uint32_t n, uint32_t aux);
+
 /* Kernel build variant for A/B measurements; 0 = default. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
