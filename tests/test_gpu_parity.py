@@ -265,6 +265,29 @@ def test_maximum_one_byte_counts(R, oracle, tex, sky):
     check(gpu_frame(R, sc, tex, sky, w, h, 2, True, cam=cam, wide_counts=False), want, 0.995)
 
 
+def test_odd_image_sizes(R, oracle, demo_scene):
+    """Texture layers that are not 256x256 / not a power of two, a skybox whose width is not a multiple of 4
+    (face = width / 4 truncates, primitives.cl:14 via raytracing.cl:62)."""
+    from example_gui_opencl_raytracer_amd.scene import Scene
+    rng = np.random.default_rng(9)
+    tex = rng.integers(0, 256, (3, 60, 100, 4), dtype=np.uint8); tex[..., 3] = 255
+    sky = rng.integers(0, 256, (1, 375, 501, 4), dtype=np.uint8); sky[..., 3] = 255
+    planes = demo_scene.planes.copy()
+    planes["material"]["texture_id"][0] = 1
+    planes["material"]["texture_scale"][0] = 23.5
+    planes["material"]["texture_id"][1] = 2                   # the mirror wall gets a texture as well
+    planes["material"]["texture_scale"][1] = 7.0
+    sc = Scene(demo_scene.spheres, planes, demo_scene.lights)
+    w, h = 160, 120
+    want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 4)
+    assert cnt.texel_fetches > 0 and cnt.sky_fetches > 0
+    got = gpu_frame(R, sc, tex, sky, w, h, 4, True)
+    if cnt.oob_reads == 0 and cnt.int_cast_oor == 0:
+        check(got, want, 0.999)
+    else:                                                       # undefined reads in the reference: both sides clamp to the edge
+        check(got, want, 0.995)
+
+
 def test_count_width_is_irrelevant(R, demo_scene, tex, sky):
     a = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=False)     # uchar counts (reference)
     b = gpu_frame(R, demo_scene, tex, sky, 96, 64, 4, True, wide_counts=True)      # 4-byte counts (extension)
