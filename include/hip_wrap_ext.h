@@ -107,7 +107,7 @@ uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity
  * op: 0 intersect_sphere {o,d,c,r -> hit,t}  1 intersect_plane {o,d,n,p0 -> hit,t}  2 reflect {i,n -> r}
  *     3 refract {n1,n2,i,n -> ok,r}  4 compute_schlick {n1,n2,i,n -> f}  5 map_to_cube {dir -> u,v bits; aux = face}
  *     6 xorshift32 {state bits -> state bits, value}  7 euclidean_modulo {a,b bits -> m bits}
- *     8 sin/cos {x -> s,c}  9 pow {x,y -> x^y}  10 normalize {v -> unit, length}. */
+ *     8 sin/cos of the sampling angle {u -> s,c of fl32(2 pi u) (aux 1) or fl32(pi u) (aux 0)}  9 pow {x,y -> x^y}  10 normalize {v -> unit, length}. */
 void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, float* out, uint32_t stride_out,
                   uint32_t n, uint32_t aux);
 
