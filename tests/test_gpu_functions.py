@@ -96,8 +96,9 @@ def _ulp_err(got, want64):
 def test_sincos_over_the_sampling_range(dev):
     """The angles are theta = fl32(2*pi*u), phi = fl32(pi*u) with u in [0,4) and an fp64 product (primitives.cl:116-125,
     raytracing.cl:99-100); the unit op takes u and returns sin/cos of that fp32 angle.  strict: OpenCL's 4 ulp.  fast
-    (hardware v_sin/v_cos on the exact revolution count + first-order correction for the angle's rounding): an ABSOLUTE
-    bound of 2e-7 -- the values only scale the light radius before being added to the light centre."""
+    (hardware v_sin/v_cos on u as the exact revolution count): an ABSOLUTE bound of 1.2e-6 = the reference's own
+    rounding of the angle (0.95e-6 rad at 8 pi) + the hardware's 1.25e-7 -- the values only scale the light radius
+    (0.1) before being added to the light centre, and the shadow ray they define has a binary outcome."""
     w, strict = dev
     rng = np.random.default_rng(11)
     u = np.concatenate([np.linspace(0, 4, 200001, dtype=np.float64)[:-1].astype(np.float32),
@@ -106,7 +107,11 @@ def test_sincos_over_the_sampling_range(dev):
     for full, scale in ((1, 2 * np.pi), (0, np.pi)):
         x = (scale * u.astype(np.float64)).astype(np.float32).astype(np.float64)
         out = w.unit(OP["sincos"], u[:, None], 2, aux=full)
-        assert np.abs(out[:, 0] - np.sin(x)).max() < 2e-7 and np.abs(out[:, 1] - np.cos(x)).max() < 2e-7
+        bound = 2e-7 if strict else 1.2e-6
+        assert np.abs(out[:, 0] - np.sin(x)).max() < bound and np.abs(out[:, 1] - np.cos(x)).max() < bound
+        if not strict:   # ... and against the unrounded angle the error is the hardware's alone
+            xe = scale * u.astype(np.float64)
+            assert np.abs(out[:, 0] - np.sin(xe)).max() < 2e-7 and np.abs(out[:, 1] - np.cos(xe)).max() < 2e-7
         if strict:
             es, ec = _ulp_err(out[:, 0], np.sin(x)), _ulp_err(out[:, 1], np.cos(x))
             small = np.abs(np.sin(x)) > 1e-3, np.abs(np.cos(x)) > 1e-3       # ulp is ill-defined at the zeros
