@@ -44,6 +44,8 @@ from example_gui_opencl_raytracer_amd.renderer import Renderer  # noqa: E402
 W, H_PER_GPU, DEPTH = 1920, 1080, 4
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak fp32 vector
+VALU_SLOT_NS = 1.04             # measured: one plain wave64 VALU instruction per SIMD (tools/ubench/valu_rates.hip)
+TRANS_WEIGHT = 3.1              # measured: a transcendental occupies 3.1 such slots
 # fp32 operations of the reference's expression trees (DESIGN.md section "flop model")
 FLOP = dict(sphere_test=34, plane_test=14, shadow_ray=40, light_shade=94, shaded_hit=73, sky=20, texel=25)
 
@@ -65,14 +67,16 @@ def profiled_traffic():
 
 
 def profiled_valu_instructions():
-    """SQ_INSTS_VALU per trace launch (wave-level VALU instructions) from the committed PMC pass."""
+    """(SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32) per trace launch (wave-level instructions) from the committed PMC passes."""
     import glob
     import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
-        m = re.search(r"^SQ_INSTS_VALU,([0-9.]+)", open(f).read(), re.M)
+        txt = open(f).read()
+        m = re.search(r"^SQ_INSTS_VALU,([0-9.]+)", txt, re.M)
+        t = re.search(r"^SQ_INSTS_VALU_TRANS_F32,([0-9.]+)", txt, re.M)
         if m:
-            best = (float(m.group(1)), os.path.basename(f))
+            best = (float(m.group(1)), float(t.group(1)) if t else 0.0, os.path.basename(f))
     return best
 
 
@@ -251,12 +255,15 @@ def main():
         }
         vi = profiled_valu_instructions() if world == 1 else None
         if vi:
-            # plain wave64 VALU instructions issue at 1.04 ns per SIMD (tools/ubench/valu_rates.hip, MI355X, 1 024 SIMDs)
-            peak = 1024 / 1.04e-9 / 1e12
-            got = vi[0] / (kernel_ms * 1e-3) / 1e12
+            # issue slots: a plain wave64 VALU instruction takes 1.04 ns of a SIMD, a transcendental (v_rcp/rsq/sqrt/
+            # sin/cos/log/exp) 3.1x that (tools/ubench/valu_rates.hip on this chip, profiles/*_valu_rates.txt); 1 024 SIMDs
+            slots = vi[0] + (TRANS_WEIGHT - 1.0) * vi[1]
+            peak = 1024 / VALU_SLOT_NS / 1e3                     # T issue slots / s
+            got = slots / (kernel_ms * 1e-3) / 1e12
             line["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(got, 4), "peak": round(peak, 4),
-                                           "unit": "T wave-instructions/s", "frac": round(got / peak, 4),
-                                           "instructions_per_launch": int(vi[0]), "source": vi[1]}
+                                           "unit": "T issue slots/s", "frac": round(got / peak, 4),
+                                           "valu_instructions_per_launch": int(vi[0]), "transcendental_per_launch": int(vi[1]),
+                                           "slot_ns": VALU_SLOT_NS, "transcendental_weight": TRANS_WEIGHT, "source": vi[2]}
         if world == 1 and not args.no_cpu_baseline:
             base, oc = cpu_baseline(sc, tex, sky)
             line["cpu_baseline"] = base

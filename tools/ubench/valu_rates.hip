@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
             if (MODE == 3) a[i] = __builtin_amdgcn_rcpf(a[i]) + 1.0f;                // v_rcp_f32 + v_add
             if (MODE == 4) a[i] = a[i] * m;                                          // v_mul_f32
             if (MODE == 5) a[i] = (a[i] > 3.0f) ? a[i] - 1.0f : a[i] + c;            // cmp + cndmask-ish
+            if (MODE == 7) a[i] = __builtin_amdgcn_sinf(a[i]) + 1.0f;                // v_sin_f32 + v_add
+            if (MODE == 8) a[i] = __builtin_amdgcn_rsqf(a[i]) + 1.0f;                // v_rsq_f32 + v_add
         }
         if (MODE == 6) { dd = dd * 1.0000001 + 1e-9; }                               // v_fma_f64 chain (1 per iter)
     }
@@ -61,6 +63,8 @@ int main() {
         run<4>("v_mul_f32 x8", 8, w);
         run<5>("cmp+sub/add+cndmask x8", 32, w);
         run<6>("v_fma_f64 x1 (dependent)", 1, w);
+        run<7>("v_sin_f32+v_add x8", 16, w);
+        run<8>("v_rsq_f32+v_add x8", 16, w);
     }
     return 0;
 }
