@@ -46,6 +46,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak fp32 vector
 VALU_SLOT_NS = 1.04             # measured: one plain wave64 VALU instruction per SIMD (tools/ubench/valu_rates.hip)
 TRANS_WEIGHT = 3.1              # measured: a transcendental occupies 3.1 such slots
+TIMING_EVERY = 8                # hipEvents around every 8th trace launch of a frame slot (an event record between two
+                                # kernels delays the second: 5 us per frame if every launch is timed)
 # fp32 operations of the reference's expression trees (DESIGN.md section "flop model")
 FLOP = dict(sphere_test=34, plane_test=14, shadow_ray=40, light_shade=94, shaded_hit=73, sky=20, texel=25)
 
@@ -186,6 +188,7 @@ def main():
     drain()
     for r in rr:
         r.w.timing_reset()
+        r.w.set_timing_every(TIMING_EVERY)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -245,7 +248,7 @@ def main():
                        "arithmetic": "strict" if args.strict else "fast", "rays_per_pixel": round(rays_step / (W * H), 4)},
             "frames_per_s": round(args.steps / elapsed, 1),
             "frames_per_s_with_readback": round(1.0 / statistics.median(rb), 1) if rb else None,
-            "trace_kernel_ms": round(kernel_ms, 4),
+            "trace_kernel_ms": round(kernel_ms, 4), "trace_launches_timed": launches,
             "lane_utilisation": round(float(tot[2].item() / max(tot[3].item(), 1.0)), 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic[0] if traffic else None,

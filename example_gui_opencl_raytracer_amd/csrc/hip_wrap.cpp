@@ -132,6 +132,7 @@ struct Impl {
     RaygenArgs sched_sig{}; int sched_sig_depth = 0; const void* sched_sig_scene = nullptr;
     /* timing log */
     std::vector<TimingEntry> timing;
+    uint32_t timing_every = 1, timing_tick = 0;   /* events around every n-th launch only */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
 };
 
@@ -200,7 +201,7 @@ std::pair<hipEvent_t, hipEvent_t> take_events(Impl* I) {
 
 struct LaunchTimer {
     Impl* I; cl_uint kernel; bool on; std::pair<hipEvent_t, hipEvent_t> ev;
-    LaunchTimer(Impl* I_, cl_uint k) : I(I_), kernel(k), on(I_->timing.size() < 16384) {
+    LaunchTimer(Impl* I_, cl_uint k) : I(I_), kernel(k), on(I_->timing.size() < 16384 && (I_->timing_tick++ % I_->timing_every) == 0) {
         if (on) { ev = take_events(I); HIP_OK(hipEventRecord(ev.first, I->stream), "Couldn't run the kernel"); }
     }
     void done() {
@@ -521,6 +522,8 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->strict = env_int("CLWRAP_STRICT", 0) ? 1 : 0;
     I->fuse = env_int("CLWRAP_FUSE", 1) ? 1 : 0;
     I->variant = env_int("CLWRAP_VARIANT", 0);
+    I->timing_every = (uint32_t)env_int("CLWRAP_TIMING_EVERY", 1);
+    if (I->timing_every == 0) I->timing_every = 1;
 
     wrap->impl = I;
     wrap->kernels_num = (cl_uint)I->kernels.size();
@@ -701,6 +704,8 @@ void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; I->sched_valid = false; }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
+
+void clw_ext_set_timing_every(cl_wrap* wrap, uint32_t n) { Impl* I = impl_of(wrap); I->timing_every = n ? n : 1; I->timing_tick = 0; }
 
 void clw_ext_timing_reset(cl_wrap* wrap) {
     Impl* I = impl_of(wrap);

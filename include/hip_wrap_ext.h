@@ -63,6 +63,10 @@ void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream);
  * there were and their summed duration in milliseconds. */
 void clw_ext_timing_reset(cl_wrap* wrap);
 void clw_ext_timing_get(cl_wrap* wrap, cl_uint kernel_id, uint32_t* launches, double* total_ms);
+/* Record the events around every n-th launch only (default 1 = every launch; env CLWRAP_TIMING_EVERY).  An event
+ * record between two kernels of a stream keeps the second from being dispatched while the first drains: at
+ * 1920x1080 depth 4 that is 5 us per 125-us frame, so a throughput loop samples (bench.py: every 8th launch). */
+void clw_ext_set_timing_every(cl_wrap* wrap, uint32_t n);
 
 /* Texture / skybox layer stack from memory instead of PNG files: `rgba` is
  * layers*h*w*4 bytes, layer-major, row-major (the image cl_wrap_load_images builds,
