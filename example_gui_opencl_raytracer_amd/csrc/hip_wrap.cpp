@@ -43,7 +43,7 @@ constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is st
 constexpr int LDS_LEVELS = 3;
 constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes beyond the reference's one-byte counts get the uniform grid (at 64 spheres it only
                                                 wins when the cells happen to align with the spheres: 9.2-15 ms vs 10.9 ms linear) */
-constexpr size_t GRID_MAX_PAIRS = (size_t)1 << 27;
+constexpr size_t GRID_MAX_PAIRS = (size_t)1 << 25;   /* 20 B per cell-list entry */
 
 [[noreturn]] void die(const char* fmt, ...) {
     va_list ap;
@@ -122,6 +122,7 @@ struct Impl {
     float* d_geom = nullptr; size_t geom_f4 = 0;
     float* d_ptex = nullptr;
     uint32_t *d_grid_start = nullptr, *d_grid_items = nullptr, *d_grid_box = nullptr;
+    float* d_grid_geom = nullptr;
     wprep_grid grid{}; bool grid_ok = false; int use_grid = 1;
     unsigned long long* d_counters = nullptr;
     /* cost-sorted tile dispatch: costs written by frame n order the tiles of frame n+1 */
@@ -315,6 +316,7 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     HIP_OK(hipMemcpy(I->d_ptex, ptex.data(), ptex.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
     /* uniform grid over the spheres for big scenes */
     for (uint32_t** q : {&I->d_grid_start, &I->d_grid_items, &I->d_grid_box}) { if (*q) { (void)hipFree(*q); *q = nullptr; } }
+    if (I->d_grid_geom) { (void)hipFree(I->d_grid_geom); I->d_grid_geom = nullptr; }
     I->grid_ok = false;
     if (ns > (uint32_t)env_int("CLWRAP_GRID_MIN", (int)GRID_MIN_SPHERES)) {   /* CLWRAP_GRID_MIN: tuning knob */
         const char* dens = getenv("CLWRAP_GRID_DENSITY");   /* tuning knob: average spheres per cell */
@@ -328,6 +330,11 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
             HIP_OK(hipMemcpy(I->d_grid_start, st.data(), st.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
             HIP_OK(hipMemcpy(I->d_grid_items, it.data(), it.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
             HIP_OK(hipMemcpy(I->d_grid_box, bx.data(), bx.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+            /* the prepared sphere of every cell-list entry, next to its index */
+            std::vector<float> cg(4 * it.size(), 0.0f);
+            for (size_t k = 0; k < pairs; k++) memcpy(&cg[4 * k], &geom[4 * (size_t)it[k]], 16);
+            HIP_OK(hipMalloc((void**)&I->d_grid_geom, cg.size() * 4), "Couldn't allocate device memory");
+            HIP_OK(hipMemcpy(I->d_grid_geom, cg.data(), cg.size() * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
             I->grid_ok = true;
         }
     }
@@ -413,7 +420,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     size_t dyn_lds = 0;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
         flags |= F_GRID;
-        P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box;
+        P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
         for (int a = 0; a < 3; a++) {
             P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
         }
@@ -644,6 +651,7 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_ptex) (void)hipFree(I->d_ptex);
     if (I->d_counters) (void)hipFree(I->d_counters);
     for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
+    if (I->d_grid_geom) (void)hipFree(I->d_grid_geom);
     if (I->d_tile_cost) (void)hipFree(I->d_tile_cost);
     if (I->d_tile_order) (void)hipFree(I->d_tile_order);
     for (auto& t : I->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }

@@ -52,6 +52,7 @@ typedef struct {
     const uint32_t* grid_start;
     const uint32_t* grid_items;
     const uint32_t* grid_box;
+    const float* grid_geom;   /* float4 per cell-list entry: geom[grid_items[k]], so a test costs one load, not two dependent ones */
     float grid_min[3], grid_inv[3], grid_cell[3];
     int32_t grid_res[3];
     /* images: RGBA8 layer stacks */
