@@ -32,7 +32,7 @@ SYMBOLS = [
     "cl_wrap_output", "cl_wrap_release",
     "clw_ext_set_depth", "clw_ext_get_depth", "clw_ext_set_strict", "clw_ext_set_fuse",
     "clw_ext_set_id_offset", "clw_ext_set_row_bands", "clw_ext_set_async", "clw_ext_sync", "clw_ext_set_stream",
-    "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_set_timing_every", "clw_ext_load_images_raw",
+    "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_set_timing_every", "clw_ext_set_pipeline", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
     "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_unit", "clw_ext_set_grid", "clw_ext_set_variant",
     "clw_host_perspective", "clw_host_write_png", "clw_host_write_png_rgba", "clw_host_read_png",
@@ -87,6 +87,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.clw_ext_set_stream.argtypes = [W, vp]
     L.clw_ext_timing_reset.argtypes = [W]
     L.clw_ext_set_timing_every.argtypes = [W, u32]
+    L.clw_ext_set_pipeline.argtypes = [W, C.c_int]
     L.clw_ext_timing_get.argtypes = [W, u32, C.POINTER(u32), C.POINTER(C.c_double)]
     L.clw_ext_load_images_raw.argtypes = [W, u32, u32, vp, u32, u32, u32]
     L.clw_ext_bind_device_buffer.argtypes = [W, u32, u32, vp, sz]
@@ -238,6 +239,7 @@ class ClWrap:
     def set_variant(self, v): self.L.clw_ext_set_variant(C.byref(self.w), int(v))
     def timing_reset(self): self.L.clw_ext_timing_reset(C.byref(self.w))
     def set_timing_every(self, n): self.L.clw_ext_set_timing_every(C.byref(self.w), int(n))
+    def set_pipeline(self, on): self.L.clw_ext_set_pipeline(C.byref(self.w), int(on))
 
     def timing_get(self, kernel_id):
         n, ms = C.c_uint32(), C.c_double()

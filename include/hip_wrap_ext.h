@@ -59,10 +59,18 @@ void clw_ext_sync(cl_wrap* wrap);
 void clw_ext_set_stream(cl_wrap* wrap, void* hip_stream);
 
 /* Per-kernel device timing from hipEvents recorded around every launch on the launch
- * stream.  reset clears the log; get waits for the logged launches and returns how many
+ * stream, from the first clw_ext_timing_reset on (a wrapper nobody asks for timings records no events).
+ * reset clears the log; get waits for the logged launches and returns how many
  * there were and their summed duration in milliseconds. */
 void clw_ext_timing_reset(cl_wrap* wrap);
 void clw_ext_timing_get(cl_wrap* wrap, cl_uint kernel_id, uint32_t* launches, double* total_ms);
+/* Pipelined read-back (default on; env CLWRAP_PIPELINE=0): a blocking cl_wrap_output that renders a frame of >= 16 MB
+ * at depth <= 4 and reads that same framebuffer back is executed as four strips, strip c being copied to the host while
+ * strip c+1 renders (3840x2160: 940 -> 1 340 frames/s).  Same pixels, same semantics -- the call returns with the whole
+ * frame in host memory.  Smaller frames and deep launches keep the single launch + single copy (measured: no gain / a
+ * loss there). */
+void clw_ext_set_pipeline(cl_wrap* wrap, int on);
+
 /* Record the events around every n-th launch only (default 1 = every launch; env CLWRAP_TIMING_EVERY).  An event
  * record between two kernels of a stream keeps the second from being dispatched while the first drains: at
  * 1920x1080 depth 4 that is 5 us per 125-us frame, so a throughput loop samples (bench.py: every 8th launch). */

@@ -204,6 +204,38 @@ def test_timing_log(R, demo_scene, tex, sky):
     r.release()
 
 
+def test_pipelined_readback_returns_the_same_frame(R, demo_scene, tex, sky):
+    """A blocking cl_wrap_output of a >= 16 MB frame at depth <= 4 renders four strips and copies each while the next renders
+    (clw_ext_set_pipeline, default on): the frame in host memory is the one the single launch + single copy gives,
+    on the first frame (no tile costs yet), on later ones (cost-sorted strips) and after a camera move."""
+    w, h = 2560, 1664
+    frames = {}
+    for on in (1, 0):
+        r = R(demo_scene, tex, sky, w, h, depth=4)
+        r.w.set_pipeline(on)
+        r.look(**CAM)
+        a = r.render().copy()
+        b = r.render().copy()
+        r.look(origin=(1.5, 2.0, -7.0), look=(0.1, -0.1, 1.0), fov=80.0, focal=1.0)
+        c = r.render().copy()
+        frames[on] = (a, b, c)
+        r.release()
+    for x, y in zip(frames[1], frames[0]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(frames[1][0], frames[1][1]) and not np.array_equal(frames[1][0], frames[1][2])
+    # a frame whose height is not a multiple of the strip granularity, and one too small to be split
+    for (ww, hh) in ((2304, 1900), (640, 480)):
+        outs = []
+        for on in (1, 0):
+            r = R(demo_scene, tex, sky, ww, hh, depth=3)
+            r.w.set_pipeline(on)
+            r.look(**CAM)
+            r.render()
+            outs.append(r.render().copy())
+            r.release()
+        assert np.array_equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------ error behaviour: print "ERROR:\t..." + exit(1)
 def _run(snippet):
     code = ("import sys; sys.path.insert(0, %r)\n"

@@ -13,6 +13,7 @@ r = Renderer(scene.render_map_scene(), textures.texture_layers(), textures.skybo
              depth=depth, strict=bool(strict))
 r.w.set_variant(variant)
 r.look(**pkg.CAMERA_RAYPNG)
+r.w.timing_reset()
 for _ in range(frames):
     r.render(readback=False)
 n, ms = r.w.timing_get(1)
