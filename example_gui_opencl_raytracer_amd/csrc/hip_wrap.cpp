@@ -36,11 +36,12 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 
 namespace {
 
-enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16 }; /* = WT_F_* of whitted_trace.inc */
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32 }; /* = WT_F_* of whitted_trace.inc */
+constexpr unsigned OCC_MIN_TILES = 100000;   /* deep launches of at least this many wavefronts take the high-occupancy flavour */
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
-constexpr int LDS_LEVELS = 3;
+constexpr int SHALLOW_LEVELS = 3;   /* DFS levels the shallow builds provide (LDS + scratch): depth <= SHALLOW_LEVELS + 1 */
 constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes beyond the reference's one-byte counts get the uniform grid (at 64 spheres it only
                                                 wins when the cells happen to align with the spheres: 9.2-15 ms vs 10.9 ms linear) */
 constexpr size_t GRID_MAX_PAIRS = (size_t)1 << 25;   /* 20 B per cell-list entry */
@@ -436,7 +437,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         } else if (I->band_stride > 1) die("Row bands need a raygen launch");
         flags |= F_RAYS;
     }
-    if (I->depth > LDS_LEVELS + 1) flags |= F_DEEP;
+    if (I->depth > SHALLOW_LEVELS + 1) flags |= F_DEEP;
     size_t dyn_lds = 0;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
         flags |= F_GRID;
@@ -479,6 +480,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
+    if ((flags & F_DEEP) && !I->strict && grid >= OCC_MIN_TILES && !(I->variant & 64)) flags |= F_OCC;
     LaunchTimer t(I, kid);
     hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
@@ -514,7 +516,7 @@ bool pipelined_output(cl_wrap* w, Impl* I, size_t array_size, size_t output_size
     /* worth it only when the copy is long and the launch is throughput-bound: measured 1.06 -> 0.745 ms at 3840x2160
      * depth 4, +3 % at 1920x1080 (four 2 MB copies are no faster than one of 8 MB), and a LOSS for deep launches,
      * where every strip would pay its own serial tail of refraction trees (0.76 -> 1.30 ms at 1280x1024 depth 15) */
-    if (n * 4 < (16u << 20) || rows < 4 * 64 || I->depth > LDS_LEVELS + 1) return false;
+    if (n * 4 < (16u << 20) || rows < 4 * 64 || I->depth > SHALLOW_LEVELS + 1) return false;
     ensure_allocated(I, out);
 
     const int nch = Impl::MAX_CHUNKS;

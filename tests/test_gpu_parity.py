@@ -331,19 +331,21 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
 
 
 def test_large_frame_is_deterministic_and_tile_order_free(R, tex, sky):
-    """4096x4096 (config C3's frame size): two renders are identical, and equal the linear-mapping build."""
+    """4096x4096 (config C3's frame size): two renders are identical, and equal the linear-mapping build (variant 2)
+    and the low-occupancy flavour of the deep build (variant 64: a launch of this size otherwise takes the flavour with
+    two DFS levels in LDS and registers capped for five waves per SIMD)."""
     from example_gui_opencl_raytracer_amd import scene
     from example_gui_opencl_raytracer_amd.renderer import Renderer
     sc = scene.dielectric_field_scene(8)
     cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
     outs = []
-    for variant in (0, 0, 2):
+    for variant in (0, 0, 2, 64):
         r = Renderer(sc, tex, sky, 4096, 4096, depth=8, strict=False)
         r.w.set_variant(variant)
         r.look(**cam)
         outs.append(r.render())
         r.release()
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
     assert len(np.unique(outs[0])) > 1000
 
 
