@@ -37,7 +37,10 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 namespace {
 
 enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32 }; /* = WT_F_* of whitted_trace.inc */
-constexpr unsigned OCC_MIN_TILES = 100000;   /* deep launches of at least this many wavefronts take the high-occupancy flavour */
+/* deep launches of at least OCC_TILES_PER_DEPTH x depth wavefronts take the high-occupancy flavour: the serial tail of
+ * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
+ * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
+constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
@@ -143,6 +146,7 @@ struct Impl {
     hipEvent_t chunk_done[MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
     /* timing log */
     std::vector<TimingEntry> timing;
+    unsigned occ_tiles_per_depth = OCC_TILES_PER_DEPTH;   /* CLWRAP_OCC_TILES_PER_DEPTH: tuning knob */
     bool timing_on = false;                       /* switched on by the first clw_ext_timing_reset / set_timing_every */
     uint32_t timing_every = 1, timing_tick = 0;   /* events around every n-th launch only */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -480,7 +484,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
-    if ((flags & F_DEEP) && !I->strict && grid >= OCC_MIN_TILES && !(I->variant & 64)) flags |= F_OCC;
+    if ((flags & F_DEEP) && !I->strict && (uint64_t)grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
     LaunchTimer t(I, kid);
     hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
@@ -604,6 +608,7 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->timing_every = (uint32_t)env_int("CLWRAP_TIMING_EVERY", 1);
     if (I->timing_every == 0) I->timing_every = 1;
     I->pipeline = env_int("CLWRAP_PIPELINE", 1) ? 1 : 0;
+    I->occ_tiles_per_depth = (unsigned)env_int("CLWRAP_OCC_TILES_PER_DEPTH", (int)OCC_TILES_PER_DEPTH);
 
     wrap->impl = I;
     wrap->kernels_num = (cl_uint)I->kernels.size();
