@@ -11,7 +11,10 @@
  * reference's behaviour.  Plain C ABI: pointers and sizes only.
  *
  * Environment variables read once by cl_wrap_init (same meaning as the setters):
- *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>
+ *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>   CLWRAP_PIPELINE=<0|1>
+ * Tuning / experiment knobs (defaults are the measured optima): CLWRAP_GRID_MIN, CLWRAP_GRID_DENSITY (uniform grid),
+ *   CLWRAP_OCC_TILES_PER_DEPTH (deep launches of >= this x depth tiles take the high-occupancy kernel flavour),
+ *   CLWRAP_TIMING_EVERY, CLWRAP_VARIANT (bit mask of clw_ext_set_variant).
  */
 #ifndef HIP_WRAP_EXT_H
 #define HIP_WRAP_EXT_H
@@ -123,7 +126,9 @@ uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity
 void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, float* out, uint32_t stride_out,
                   uint32_t n, uint32_t aux);
 
-/* Kernel build variant for A/B measurements; 0 = default. */
+/* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
+ * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
+ * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
 /* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
