@@ -2,8 +2,9 @@
 
 Bars (written here as the tolerances):
   strict build  (no contraction, IEEE divide/sqrt)   >= 99.9 % of pixels bit-exact, ray counts equal
-  fast build    (FMA contraction, native rcp/sqrt)   >= 99.5 % bit-exact, >= 99.8 % within 1 LSB per
-                                                     channel, float radiance within 1e-4 on >= 99.5 %
+  fast build    (explicit FMAs, native rcp/sqrt, ...)  >= 99.8 % bit-exact, >= 99.9 % within 1 LSB per channel on
+                                                     render.map frames (99.9 / 99.95 % at the full C2 size; looser on
+                                                     the chaotic glass-field scene), float radiance within 1e-4 on >= 99.5 %
   integer / index work (raygen records are fp but must be bit-exact; ids, packing) bit-exact.
 """
 import numpy as np
@@ -48,7 +49,7 @@ def test_strict_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w,
 @pytest.mark.parametrize("w,h,depth", [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)])
 def test_fast_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w, h, depth):
     got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=False)
-    check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.995, 0.998)
+    check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.998, 0.999)
 
 
 def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
@@ -311,11 +312,11 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
     w, h, depth = 1920, 1080, 4
     want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky4k, depth)
     assert 13.8 < cnt.rays / (w * h) < 13.95                      # 13.88 rays/px
-    for strict, bar in ((True, 0.9995), (False, 0.995)):
+    for strict, bar in ((True, 0.9995), (False, 0.999)):
         r = Renderer(demo_scene, tex, sky4k, w, h, depth=depth, strict=strict)
         r.look(**CAM)
         got = r.render()
-        check(got, want, bar, None if strict else 0.998)
+        check(got, want, bar, None if strict else 0.9995)
         r.w.enable_counters(1)
         r.render(readback=False)
         c = r.w.read_counters()
