@@ -35,6 +35,7 @@ SYMBOLS = [
     "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_set_timing_every", "clw_ext_set_pipeline", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
     "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_unit", "clw_ext_set_grid", "clw_ext_set_variant",
+    "clw_ext_invalidate_scene", "clw_ext_read_counters_ex", "clw_ext_unit_scene",
     "clw_host_perspective", "clw_host_write_png", "clw_host_write_png_rgba", "clw_host_read_png",
     "clw_host_free", "clw_ext_version",
 ]
@@ -98,6 +99,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.clw_ext_read_tile_costs.argtypes = [W, vp, u32]
     L.clw_ext_read_tile_costs.restype = u32
     L.clw_ext_read_counters.argtypes = [W, C.POINTER(C.c_uint64 * 8)]
+    L.clw_ext_read_counters_ex.argtypes = [W, C.POINTER(C.c_uint64 * 12), u32]
+    L.clw_ext_invalidate_scene.argtypes = [W]
+    L.clw_ext_unit_scene.argtypes = [W, u32, C.c_int, vp, u32, vp, u32, u32]
     L.clw_host_perspective.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float, C.c_float, u32, u32,
                                        C.POINTER(clw_camera)]
     L.clw_host_perspective.restype = C.c_int
@@ -260,8 +264,19 @@ class ClWrap:
     def enable_counters(self, on): self.L.clw_ext_enable_counters(C.byref(self.w), int(on))
 
     def read_counters(self):
-        out = (C.c_uint64 * 8)()
-        self.L.clw_ext_read_counters(C.byref(self.w), C.byref(out))
+        """Work counters of the counting build (clw_ext_read_counters_ex); `shadow_rays` counts every shadow ray the
+        reference would cast, `shadow_rays_traced` leaves out the ones elided on zero-coefficient surfaces."""
+        out = (C.c_uint64 * 12)()
+        self.L.clw_ext_read_counters_ex(C.byref(self.w), C.byref(out), 12)
         names = ["segments", "shadow_rays", "light_probes", "sky_fetches", "texel_fetches", "pushes",
-                 "lane_iters", "wave_iters_x64"]
+                 "lane_iters", "wave_iters_x64", "shadow_rays_traced"]
         return dict(zip(names, [int(x) for x in out]))
+
+    def invalidate_scene(self): self.L.clw_ext_invalidate_scene(C.byref(self.w))
+
+    def unit_scene(self, op: int, rows: np.ndarray, out_cols: int, kernel_id: int = 1) -> np.ndarray:
+        """Run one scene-dependent device helper (see clw_ext_unit_scene) over float32 rows -> float32 [n, out_cols]."""
+        rows = np.ascontiguousarray(rows, np.float32)
+        out = np.zeros((rows.shape[0], out_cols), np.float32)
+        self.L.clw_ext_unit_scene(C.byref(self.w), kernel_id, op, _ptr(rows), rows.shape[1], _ptr(out), out_cols, rows.shape[0])
+        return out

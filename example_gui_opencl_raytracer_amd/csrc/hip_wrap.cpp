@@ -32,6 +32,8 @@ extern "C" hipError_t wt_strict_launch_trace(const whitted_params*, int, unsigne
 extern "C" hipError_t wt_strict_launch_raygen(const raygen_params*, hipStream_t);
 extern "C" hipError_t wt_fast_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 extern "C" hipError_t wt_strict_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
+extern "C" hipError_t wt_fast_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
+extern "C" hipError_t wt_strict_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
 extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, hipStream_t);
 
 namespace {
@@ -76,6 +78,13 @@ struct RaygenArgs { /* snapshot of the eight by-value raygen arguments + the lau
     uint32_t n_items;
     uint32_t band_stride, band_phase;
 };
+/* field by field (the struct has tail padding, which a memcmp would also compare); floats by bit pattern */
+bool same_raygen(const RaygenArgs& a, const RaygenArgs& b) {
+    return !memcmp(a.corner, b.corner, 12) && !memcmp(a.origin, b.origin, 12) && !memcmp(a.up, b.up, 12) &&
+           !memcmp(a.right, b.right, 12) && !memcmp(&a.w_factor, &b.w_factor, 4) && !memcmp(&a.h_factor, &b.h_factor, 4) &&
+           a.width == b.width && a.height == b.height && a.id_offset == b.id_offset && a.n_items == b.n_items &&
+           a.band_stride == b.band_stride && a.band_phase == b.band_phase;
+}
 
 struct Buffer {
     void* dptr = nullptr;
@@ -125,6 +134,7 @@ struct Impl {
     uint32_t prep_ns = 0, prep_np = 0, prep_nl = 0;
     float* d_geom = nullptr; size_t geom_f4 = 0;
     float* d_ptex = nullptr;
+    uint64_t scene_generation = 0;   /* bumped every time the prepared scene is rebuilt (device pointers can be reused) */
     uint32_t *d_grid_start = nullptr, *d_grid_items = nullptr, *d_grid_box = nullptr;
     float* d_grid_geom = nullptr;
     wprep_grid grid{}; bool grid_ok = false; int use_grid = 1;
@@ -135,7 +145,7 @@ struct Impl {
         unsigned* cost = nullptr; unsigned* order = nullptr;
         uint32_t w = 0, rows = 0;
         bool valid = false;
-        RaygenArgs sig{}; int sig_depth = 0; const void* sig_scene = nullptr;
+        RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0;   /* camera, depth and scene generation of `order` */
     };
     static constexpr int MAX_CHUNKS = 4;
     Sched scheds[1 + MAX_CHUNKS];   /* [0]: whole-range launches; [1 + c]: strip c of a pipelined read-back */
@@ -354,12 +364,41 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
         }
     }
     I->geom_f4 = f4;
+    I->scene_generation++;
     I->prep_s = s; I->prep_p = p; I->prep_l = l; I->prep_ns = ns; I->prep_np = np; I->prep_nl = nl;
 }
 
 Buffer* buffer_arg(cl_wrap* w, cl_uint kernel_id, cl_uint arg) {
     if (!is_registered(w, kernel_id, arg)) die("Couldn't run the kernel");
     return (Buffer*)w->buffers[kernel_id][arg];
+}
+
+/* The scene side of a raytracer launch (args 1-6, 8, 9 of kernel `kid`): checks the bindings, prepares the geometry
+ * (once per scene) and fills the scene fields of P; chooses between the uniform grid, LDS-staged geometry and
+ * geometry read from global memory (flags F_GRID / F_GEOM_LDS, dynamic LDS bytes). */
+void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags, size_t& dyn_lds) {
+    Kernel& k = I->kernels[kid];
+    Buffer* bs = buffer_arg(w, kid, 1);
+    Buffer* bp = buffer_arg(w, kid, 2);
+    Buffer* bl = buffer_arg(w, kid, 3);
+    uint32_t ns = read_count(k, 4), np = read_count(k, 5), nl = read_count(k, 6);
+    Buffer* tex = buffer_arg(w, kid, 8);
+    Buffer* sky = buffer_arg(w, kid, 9);
+    if (!tex->image || !sky->image) die("Couldn't run the kernel");
+    prepare_scene(I, bs, ns, bp, np, bl, nl);
+    ensure_allocated(I, bs); ensure_allocated(I, bp);
+    P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
+    P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
+    P.ns = ns; P.np = np; P.nl = nl;
+    P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
+    P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
+    if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
+        flags |= F_GRID;
+        P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
+        for (int a = 0; a < 3; a++) {
+            P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
+        }
+    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
 }
 
 /* one strip of a frame: rows [row0, row0 + rows) of the launch range, scheduling state in scheds[slot] */
@@ -376,15 +415,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         rays = lookup_handle(I, h);
         if (!rays) die("Couldn't run the kernel");
     }
-    Buffer* bs = buffer_arg(w, kid, 1);
-    Buffer* bp = buffer_arg(w, kid, 2);
-    Buffer* bl = buffer_arg(w, kid, 3);
-    uint32_t ns = read_count(k, 4), np = read_count(k, 5), nl = read_count(k, 6);
     uint32_t total; memcpy(&total, need_value(k, 7, 4, 4).bytes, 4);
-    Buffer* tex = buffer_arg(w, kid, 8);
-    Buffer* sky = buffer_arg(w, kid, 9);
     Buffer* out = buffer_arg(w, kid, 10);
-    if (!tex->image || !sky->image) die("Couldn't run the kernel");
 
     uint64_t rounded = ((uint64_t)array_size + BLOCK - 1) / BLOCK * BLOCK;
     uint64_t n64 = rounded < total ? rounded : total;      /* guard `id >= total_size` (raytracing.cl:24) */
@@ -393,22 +425,16 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     if (n64 == 0) return;
     if (n64 > 0xFFFFFFFFull) die("Couldn't run the kernel");
 
-    prepare_scene(I, bs, ns, bp, np, bl, nl);
-    ensure_allocated(I, bs); ensure_allocated(I, bp);
-
     whitted_params P{};
+    int flags = 0;
+    size_t dyn_lds = 0;
+    bind_scene(w, I, kid, P, flags, dyn_lds);
     P.n_items = (uint32_t)n64;
     P.depth = I->depth;
-    P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
-    P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
-    P.ns = ns; P.np = np; P.nl = nl;
-    P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
-    P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
     P.out = (uint32_t*)out->dptr;
     P.out_rgb = I->debug_rgb;
     P.coop_max = (I->variant & 16) ? 0u : 10u;
 
-    int flags = 0;
     const bool fused = I->fuse && rays->gen_valid;
     RaygenArgs g{};
     if (fused) {
@@ -442,19 +468,11 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         flags |= F_RAYS;
     }
     if (I->depth > SHALLOW_LEVELS + 1) flags |= F_DEEP;
-    size_t dyn_lds = 0;
-    if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
-        flags |= F_GRID;
-        P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
-        for (int a = 0; a < 3; a++) {
-            P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
-        }
-    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
     if (I->counting) {
         flags |= F_COUNT;
         if (!I->d_counters) {
-            HIP_OK(hipMalloc((void**)&I->d_counters, 8 * sizeof(unsigned long long)), "Couldn't allocate device memory");
-            HIP_OK(hipMemsetAsync(I->d_counters, 0, 8 * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
+            HIP_OK(hipMalloc((void**)&I->d_counters, CLW_NUM_COUNTERS * sizeof(unsigned long long)), "Couldn't allocate device memory");
+            HIP_OK(hipMemsetAsync(I->d_counters, 0, CLW_NUM_COUNTERS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
         }
         P.counters = I->d_counters;
     }
@@ -477,9 +495,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             P.tile_cost = S.cost;
             P.tile_order = S.valid ? S.order : nullptr;
             /* the costs can only change when the camera, the depth or the scene did */
-            sched_rebuild = !S.valid || memcmp(&g, &S.sig, sizeof g) != 0 || S.sig_depth != I->depth ||
-                            S.sig_scene != (const void*)I->d_geom;
-            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->d_geom; }
+            sched_rebuild = !S.valid || !same_raygen(g, S.sig) || S.sig_depth != I->depth || S.sig_scene != I->scene_generation;
+            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; }
         }
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -779,6 +796,31 @@ void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, fl
     HIP_OK(hipMemcpy(out, dout, (size_t)n * stride_out * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
     (void)hipFree(din); (void)hipFree(dout);
 }
+void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* in, uint32_t stride_in, float* out,
+                        uint32_t stride_out, uint32_t n) {
+    Impl* I = impl_of(wrap);
+    use_device(I);
+    check_kernel_id(wrap, kernel_id);
+    if (I->kernels[kernel_id].kind != K_RAYTRACER) die("Wrong kernel ID given");
+    if (n == 0) return;
+    whitted_params P{};
+    int flags = 0;
+    size_t dyn_lds = 0;
+    bind_scene(wrap, I, kernel_id, P, flags, dyn_lds);
+    P.depth = I->depth;
+    float *din = nullptr, *dout = nullptr;
+    HIP_OK(hipMalloc((void**)&din, (size_t)n * stride_in * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMalloc((void**)&dout, (size_t)n * stride_out * 4), "Couldn't allocate device memory");
+    HIP_OK(hipMemcpy(din, in, (size_t)n * stride_in * 4, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    HIP_OK(hipMemset(dout, 0, (size_t)n * stride_out * 4), "Couldn't allocate device memory");
+    HIP_OK(hipDeviceSynchronize(), "The device kernel failed");
+    hipError_t e = I->strict ? wt_strict_launch_unit_scene(&P, flags, op, din, dout, n, stride_in, stride_out, dyn_lds, I->stream)
+                             : wt_fast_launch_unit_scene(&P, flags, op, din, dout, n, stride_in, stride_out, dyn_lds, I->stream);
+    if (e != hipSuccess) die("Couldn't run the kernel");
+    finish(I);
+    HIP_OK(hipMemcpy(out, dout, (size_t)n * stride_out * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    (void)hipFree(din); (void)hipFree(dout);
+}
 uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity) {
     Impl* I = impl_of(wrap);
     use_device(I);
@@ -841,6 +883,13 @@ void clw_ext_bind_device_buffer(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id
     register_buffer(wrap, kernel_id, arg_id, b);
 }
 
+void clw_ext_invalidate_scene(cl_wrap* wrap) {
+    Impl* I = impl_of(wrap);
+    I->prep_s = I->prep_p = I->prep_l = nullptr;
+    /* a scene buffer rewritten in place on the device no longer matches its host copy */
+    for (Buffer* b : I->live) if (!b->image) b->shadow.clear();
+}
+
 void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id) {
     Impl* I = impl_of(wrap);
     use_device(I);
@@ -854,18 +903,19 @@ void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id) {
 
 void clw_ext_enable_counters(cl_wrap* wrap, int enable) { impl_of(wrap)->counting = enable ? 1 : 0; }
 
-void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]) {
+void clw_ext_read_counters_ex(cl_wrap* wrap, uint64_t* out, uint32_t n) {
     Impl* I = impl_of(wrap);
     use_device(I);
     finish(I);
-    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (uint32_t k = 0; k < n; k++) out[k] = 0;
     if (!I->d_counters) return;
-    unsigned long long h[8];
+    unsigned long long h[CLW_NUM_COUNTERS];
     HIP_OK(hipMemcpy(h, I->d_counters, sizeof h, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
     HIP_OK(hipMemsetAsync(I->d_counters, 0, sizeof h, I->stream), "Couldn't allocate device memory");
     finish(I);
-    for (int k = 0; k < 8; k++) out[k] = h[k];
+    for (uint32_t k = 0; k < n && k < CLW_NUM_COUNTERS; k++) out[k] = h[k];
 }
+void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]) { clw_ext_read_counters_ex(wrap, out, 8); }
 
 int clw_host_write_png(const char* path, const uint32_t* xrgb, uint32_t width, uint32_t height) {
     return wpng_write_xrgb(path, xrgb, width, height, 1);

@@ -48,11 +48,13 @@ int wpng_read_rgba(const char* path, uint32_t* width, uint32_t* height, uint8_t*
             w = be32(ih); h = be32(ih + 4);
             if (ih[8] != 8 || ih[9] != 2) { rc = WPNG_ERR_FORMAT; break; }      /* depth 8, colour type RGB */
             if (ih[10] != 0 || ih[11] != 0 || ih[12] != 0) { rc = WPNG_ERR_UNSUPPORTED; break; } /* interlace */
-            if (w == 0 || h == 0) { rc = WPNG_ERR_CORRUPT; break; }
+            /* the PNG limit is 2^31 - 1 per side; the products below must also fit size_t and zlib's uLong */
+            if (w == 0 || h == 0 || w > 0x7FFFFFFFu || h > 0x7FFFFFFFu) { rc = WPNG_ERR_CORRUPT; break; }
+            if ((size_t)h > SIZE_MAX / ((size_t)w * 4 + 1)) { rc = WPNG_ERR_CORRUPT; break; }
             have_ihdr = 1;
             fseek(fp, 4, SEEK_CUR);
         } else if (!memcmp(ch + 4, "IDAT", 4)) {
-            if (!have_ihdr) { rc = WPNG_ERR_CORRUPT; break; }
+            if (!have_ihdr || len > 0x7FFFFFFFu) { rc = WPNG_ERR_CORRUPT; break; }
             if (idat_len + len > idat_cap) {
                 idat_cap = (idat_len + len) * 2 + 4096;
                 unsigned char* n = (unsigned char*)realloc(idat, idat_cap);
@@ -65,7 +67,7 @@ int wpng_read_rgba(const char* path, uint32_t* width, uint32_t* height, uint8_t*
         } else if (!memcmp(ch + 4, "IEND", 4)) {
             done = 1;
         } else {
-            if (fseek(fp, (long)len + 4, SEEK_CUR) != 0) { rc = WPNG_ERR_CORRUPT; break; }
+            if (len > 0x7FFFFFFFu || fseek(fp, (long)len + 4, SEEK_CUR) != 0) { rc = WPNG_ERR_CORRUPT; break; }
         }
     }
     fclose(fp);

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
+#define CLW_NUM_COUNTERS 12 /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex) */
 
 typedef struct {
     /* camera: the eight by-value raygen arguments (reference raygen.cl:5-8) */
@@ -62,7 +63,7 @@ typedef struct {
     const float* rays;     /* unfused path: 64-B rray records, else NULL              */
     uint32_t* out;         /* packed 0x00RRGGBB per work-item                         */
     float* out_rgb;        /* optional float radiance, 3 per work-item                */
-    unsigned long long* counters; /* counting build only: 8 words                     */
+    unsigned long long* counters; /* counting build only: CLW_NUM_COUNTERS words          */
 } whitted_params;
 
 typedef struct {

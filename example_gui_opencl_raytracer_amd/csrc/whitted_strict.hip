@@ -13,4 +13,5 @@
 #define WT_LAUNCH_RAYGEN wt_strict_launch_raygen
 #define WT_LAUNCH_SCHED wt_strict_launch_sched
 #define WT_LAUNCH_UNIT wt_strict_launch_unit
+#define WT_LAUNCH_UNIT_SCENE wt_strict_launch_unit_scene
 #include "whitted_launch.inc"

@@ -88,6 +88,10 @@ void clw_ext_load_images_raw(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, c
 /* Register caller-owned device memory as buffer argument `arg_id` (not freed by release). */
 void clw_ext_bind_device_buffer(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id, void* device_ptr,
                                 size_t size);
+/* The scene arrays (raytracer args 1-3) are SNAPSHOTTED when first traced: the shim derives its prepared geometry
+ * (and, for big scenes, the uniform grid) from them once per (buffers, counts).  A caller that rewrites a bound or
+ * uploaded scene buffer in place calls this to have the next launch prepare the scene again. */
+void clw_ext_invalidate_scene(cl_wrap* wrap);
 /* Device address of a buffer argument (allocates a lazily created buffer). */
 void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id);
 
@@ -102,6 +106,11 @@ void clw_ext_set_debug_rgb(cl_wrap* wrap, void* device_ptr_f32x3);
  * (rays = out[0] + out[1]; out[6]/out[7] = SIMD lane utilisation). */
 void clw_ext_enable_counters(cl_wrap* wrap, int enable);
 void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
+/* The same with the later words: out[8] = shadow rays really TRACED.  out[1] counts every shadow ray the reference
+ * would cast; those of a surface whose specular and diffuse coefficients are both zero (glass)
+ * contribute exactly +0, so the kernel draws their random numbers but does not trace them -- out[8] leaves them
+ * out.  n <= 12 words are returned (the rest reads 0), and the device block is cleared. */
+void clw_ext_read_counters_ex(cl_wrap* wrap, uint64_t* out, uint32_t n);
 
 /* Uniform grid over the spheres (default on; built for scenes with more than 256 spheres): rays test only the
  * spheres registered in the cells they cross instead of all of them.  Same arithmetic per test, same nearest
@@ -125,6 +134,17 @@ uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity
  *     8 sin/cos of the sampling angle {u -> s,c of fl32(2 pi u) (aux 1) or fl32(pi u) (aux 0)}  9 pow {x,y -> x^y}  10 normalize {v -> unit, length}. */
 void clw_ext_unit(cl_wrap* wrap, int op, const float* in, uint32_t stride_in, float* out, uint32_t stride_out,
                   uint32_t n, uint32_t aux);
+
+/* The same for the helpers that need the SCENE: runs on the scene bound to raytracer kernel `kernel_id` (its args 1-6,
+ * 8, 9), through the code the trace kernel itself runs (its hit phase and its batched shadow traversal).
+ * op: 0 hit phase {o,d -> lit, light rgb[3], solid hit, point[3], normal[3], material rgb[3], ambient, diffuse, specular,
+ *       shininess, transparent, dielectric, n, reflectivity}  (findLightIntersection + findSolidIntersection,
+ *       reference primitives.cl:262-318, 322-394; 22 floats out)
+ *     1 testShadowPath {to, from -> factor}  (primitives.cl:396-442)
+ *     2 plane_texture_pixel {b0[3], scale, b1[3], texture id bits, p[3] -> rgb}  (primitives.cl:217-259; the first eight
+ *       floats are the plane's prepared basis row; stride_in must be a multiple of 4). */
+void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* in, uint32_t stride_in, float* out,
+                        uint32_t stride_out, uint32_t n);
 
 /* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
