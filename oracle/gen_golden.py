@@ -11,6 +11,13 @@ Outputs (inputs and expected outputs only -- no reference source in any form):
                             camera of raypng.c:17-21, procedural textures (textures.py),
                             skybox_cross(512): 160x120 at depth 1, 4, 15 and 320x240 at depth 4;
                             plus the 64-byte ray records of `raygen` for 160x120.
+  tests/golden/masks.npz    per frame, bit-packed pixel masks of where the reference's output is DISCONTINUOUS or
+                            ill-conditioned (make_masks below): `fma` = two legal builds of the reference kernels
+                            (contraction off / on) disagree, dilated 1 px; `jitter` = the oracle's float radiance is
+                            not locally linear under camera shifts of 1/64, 1/256, 1/1024 px; `margin` = a sphere
+                            discriminant or a texel-index truncation is decided within rounding error.
+  tests/golden/camera.npz   inputs and outputs of the reference's own rinit_camera + rgen_perspective
+                            (src/cpu_ray.c:24-35, 42-106, built into oracle/_ref/libref_cpu_ray.so).
   tests/golden/vectors.npz  seeded random inputs and the reference's outputs for
                             intersect_sphere, intersect_plane, reflect, refract,
                             compute_schlick, map_to_cube, xorshift32, euclidean_modulo,
@@ -29,12 +36,72 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from example_gui_opencl_raytracer_amd import scene as S, textures as T  # noqa: E402
-from oracle.oracle_py import Oracle, Reference, _f3, _p  # noqa: E402
+from oracle.oracle_py import (MARGIN_SITES, REF_FMA_SO, Oracle, RefCamera, Reference, _f3, _p, render_margins,  # noqa: E402
+                              shifted_camera)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 CAM = dict(origin=(0.8, 2.5, -8.0), look=(0.2, 0.0, 1.0))
-FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)]
+FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4), (640, 480, 1)]   # the last one is BASELINE config C1
+MASK_ONLY_FRAMES = [(1280, 720, 4)]   # too big to commit as pixels: mask + CRC of the reference frame
 N = 2000
+
+JITTERS = (1.0 / 64, 1.0 / 256, 1.0 / 1024)   # camera shifts in pixels
+JITTER_TAU = 2e-5                              # |f(p+v) + f(p-v) - 2 f(p)| above this = not locally linear
+DISC_MARGIN, CAST_MARGIN = 1e-5, 2e-6          # relative decision margins counted as "within rounding error"
+
+# cameras for the rgen_perspective fixtures: the two drivers' own, then assorted positions / fields of view / sizes
+CAMERAS = [((0.8, 2.5, -8.0), (0.2, 0.0, 1.0), 90.0, 1.0, 800, 600),        # raypng.c:17-21
+           ((0.8, 2.5, -8.0), (0.0, 0.0, 1.0), 90.0, 1.0, 800, 600),        # rayinteractive.c:111-115
+           ((0.8, 2.5, -8.0), (0.2, 0.0, 1.0), 90.0, 1.0, 1920, 1080),
+           ((0.8, 2.5, -8.0), (0.2, 0.0, 1.0), 90.0, 1.0, 640, 480),
+           ((-3.0, 0.6, 0.5), (1.0, 0.05, 0.3), 70.0, 1.0, 1280, 720),
+           ((0.9, 0.7, 1.4), (0.3, -0.2, 1.0), 100.0, 0.5, 8192, 8192),
+           ((1.0, 9.0, 1.0), (0.01, -1.0, 0.02), 60.0, 2.0, 4096, 4096),
+           ((3.5, 3.0, -6.0), (0.0, -2.5, 9.5), 90.0, 1.0, 333, 77),
+           ((0.0, 12.0, -10.0), (0.0, -0.45, 1.0), 120.0, 1.0, 1920, 1080),
+           ((5.0, 1.0, 5.0), (-1.0, 0.0, -1.0), 35.0, 1.0, 160, 120),
+           ((0.0, 0.0, 0.0), (0.0, 0.999, 0.04), 45.0, 1.0, 64, 48),         # almost straight up
+           ((0.0, 0.0, 0.0), (0.0, -1.0, 0.0), 90.0, 1.0, 64, 48)]           # straight down (accepted: only +Y is rejected)
+
+
+def channel_diff(a, b):
+    ca = np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], 1).astype(np.int32)
+    cb = np.stack([(b >> 16) & 255, (b >> 8) & 255, b & 255], 1).astype(np.int32)
+    return np.abs(ca - cb).max(1)
+
+
+def dilate1(m, w, h):
+    """3x3 dilation of a boolean image."""
+    m = m.reshape(h, w)
+    p = np.pad(m, 1)
+    out = np.zeros_like(m)
+    for dy in range(3):
+        for dx in range(3):
+            out |= p[dy:dy + h, dx:dx + w]
+    return out.reshape(-1)
+
+
+def make_masks(ref, ref_fma, orc, cam, sc, tex, sky, depth):
+    """The three discontinuity masks of one frame -> (reference frame, dict of boolean arrays)."""
+    w, h = cam.width, cam.height
+    a, oob = ref.render(cam, sc, tex, sky, depth)
+    b, _ = ref_fma.render(cam, sc, tex, sky, depth)
+    assert oob == 0
+    fma = dilate1(channel_diff(a, b) > 0, w, h)
+    o0, r0, _ = orc.render(cam, sc, tex, sky, depth, want_rgb=True)
+    assert np.array_equal(o0, a), "the restatement must equal the reference kernels bit for bit"
+    jit = np.zeros(w * h, bool)
+    for delta in JITTERS:
+        for dx, dy in ((delta, 0.0), (0.0, delta)):
+            _, rp, _ = orc.render(shifted_camera(cam, dx, dy), sc, tex, sky, depth, want_rgb=True)
+            _, rm, _ = orc.render(shifted_camera(cam, -dx, -dy), sc, tex, sky, depth, want_rgb=True)
+            with np.errstate(invalid="ignore"):
+                jit |= np.nan_to_num(np.abs(rp + rm - 2 * r0).max(1), nan=1e9) > JITTER_TAU
+    om, mar = render_margins(cam, sc, tex, sky, depth)
+    assert np.array_equal(om, a)
+    margin = (mar[:, MARGIN_SITES.index("disc")] < DISC_MARGIN) | (mar[:, MARGIN_SITES.index("cast")] < CAST_MARGIN)
+    return a, dict(fma=fma, jitter=jit, margin=margin)
+
 
 
 def unit(rng, n):
@@ -88,15 +155,29 @@ def main():
         raise SystemExit("oracle/_ref/libref_cl.so is missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(GOLD, exist_ok=True)
     ref, orc = Reference(), Oracle()
+    ref_fma = Reference(REF_FMA_SO)
     sc = S.render_map_scene()
     tex, sky = T.texture_layers(), T.skybox_cross(512)
 
-    frames = {}
-    for (w, h, depth) in FRAMES:
+    import zlib
+    frames, masks = {}, {}
+    for (w, h, depth) in FRAMES + MASK_ONLY_FRAMES:
         cam = orc.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
-        img, oob = ref.render(cam, sc, tex, sky, depth)
-        assert oob == 0, "golden scene must not read outside the images"
-        frames[f"render_map_{w}x{h}_d{depth}"] = img
+        img, mk = make_masks(ref, ref_fma, orc, cam, sc, tex, sky, depth)
+        key = f"render_map_{w}x{h}_d{depth}"
+        if (w, h, depth) in FRAMES:
+            frames[key] = img
+        for name, m in mk.items():
+            masks[f"{key}_{name}"] = np.packbits(m)
+        masks[f"{key}_crc32"] = np.array([zlib.crc32(img.tobytes())], np.uint32)
+        un = mk["fma"] | mk["jitter"] | mk["margin"]
+        print(f"{key}: masks fma {mk['fma'].mean():.4f} jitter {mk['jitter'].mean():.4f} margin {mk['margin'].mean():.4f} union {un.mean():.4f}")
+    np.savez_compressed(os.path.join(GOLD, "masks.npz"), **masks)
+
+    rc = RefCamera()
+    cin = np.array([list(o) + list(l) + [fov, focal, w, h] for (o, l, fov, focal, w, h) in CAMERAS], np.float64)
+    cout = np.stack([rc.perspective(o, l, fov, focal, w, h) for (o, l, fov, focal, w, h) in CAMERAS])
+    np.savez_compressed(os.path.join(GOLD, "camera.npz"), inputs=cin, outputs=cout)
     cam = orc.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 160, 120)
     frames["raygen_160x120"] = ref.raygen(cam)
     frames["camera_160x120"] = np.frombuffer(bytes(cam), np.uint8).copy()
@@ -167,7 +248,7 @@ def main():
     sm[:, 3] = 0; sm[:, 14:] = 0   # struct padding is not part of the contract
     out["solid_hit"], out["solid_point"], out["solid_normal"], out["solid_material"] = sh_, sp, sn, sm
     np.savez_compressed(os.path.join(GOLD, "vectors.npz"), **out)
-    for f in ("frames.npz", "vectors.npz"):
+    for f in ("frames.npz", "vectors.npz", "masks.npz", "camera.npz"):
         print(f, os.path.getsize(os.path.join(GOLD, f)), "bytes")
 
 

@@ -16,6 +16,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libref_cl.so")
+REF_FMA_SO = os.path.join(HERE, "_ref", "libref_cl_fma.so")      # the same kernels built with FMA contraction
+REF_CAMERA_SO = os.path.join(HERE, "_ref", "libref_cpu_ray.so")  # the reference's src/cpu_ray.c (host camera code)
+MARGINS_SO = os.path.join(HERE, "liboracle_margins.so")         # the restatement with its decision-margin tracker
 
 c_f = C.c_float
 c_fp = C.POINTER(C.c_float)
@@ -164,6 +167,51 @@ class Oracle:
         if rc:
             raise ValueError("wo_trace_rays: bad depth / id range")
         return out, cnt
+
+
+def shifted_camera(cam: Camera, dx: float, dy: float) -> Camera:
+    """The camera whose pixel (x, y) samples where `cam` samples (x + dx, y + dy): a sub-pixel shift of the image
+    corner along the camera's own right / up steps (raygen.cl:13-17).  Used for the jitter masks of tests/golden."""
+    c = Camera.from_buffer_copy(bytes(cam))
+    for k in range(3):
+        c.im_corner[k] = np.float32(np.float64(cam.im_corner[k]) + np.float64(cam.right[k]) * np.float64(cam.w_factor) * dx
+                                    - np.float64(cam.up[k]) * np.float64(cam.h_factor) * dy)
+    return c
+
+
+MARGIN_SITES = ["disc", "root", "plane", "nearest", "shadow_t", "cast", "face", "tir"]   # WO_M_* of whitted_oracle.c
+
+
+def render_margins(cam: Camera, scene, tex, sky, depth):
+    """-> (uint32[n] frame, float32[n, 8] smallest relative decision margin per site class); diagnostic build."""
+    L = C.CDLL(MARGINS_SO)
+    L.wo_render_margins.restype = C.c_int
+    L.wo_render_margins.argtypes = [C.POINTER(Camera), C.POINTER(SceneC), C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    inp = _Inputs(scene, tex, sky)
+    n = cam.width * cam.height
+    out = np.zeros(n, np.uint32)
+    mar = np.ones((n, len(MARGIN_SITES)), np.float32)
+    if L.wo_render_margins(C.byref(cam), C.byref(inp.c), depth, 0, n, _p(out), _p(mar)):
+        raise ValueError("wo_render_margins: bad depth")
+    return out, mar
+
+
+class RefCamera:
+    """rinit_camera + rgen_perspective of the reference's own src/cpu_ray.c (built by oracle/Makefile)."""
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_CAMERA_SO)
+
+    def __init__(self, path: str = REF_CAMERA_SO):
+        self.lib = C.CDLL(path)
+        self.lib.ref_perspective.argtypes = [c_f * 3, c_f * 3, c_f, c_f, C.c_uint, C.c_uint, c_f * 14]
+
+    def perspective(self, origin, look, fov, focal, width, height) -> np.ndarray:
+        """-> float32[14]: im_corner, origin, up, right, w_factor, h_factor"""
+        out = (c_f * 14)()
+        self.lib.ref_perspective(_f3(origin), _f3(look), fov, focal, width, height, out)
+        return np.array(out[:], np.float32)
 
 
 class Reference:

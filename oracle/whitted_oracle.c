@@ -44,6 +44,28 @@
 
 typedef struct { float x, y, z; } v3;
 
+/* ---- decision margins (diagnostic build only: -DWO_MARGINS -> liboracle_margins.so) -------------------------------
+ * Every comparison whose outcome selects a different code path or a different texel records how close its operands
+ * were, as a relative margin |a - b| / (|a| + |b|); wo_render_margins returns the per-pixel minimum per site class.
+ * A pixel with a margin near the rounding error (2^-24) is one where two correct evaluations of the reference may
+ * legitimately disagree: tests/golden/masks.npz uses this for the ill-conditioned sphere discriminants that a
+ * sub-pixel jitter of the camera cannot expose (far origins: b*b and 4ac agree to 7 digits, their difference is
+ * rounding noise).  The plain build compiles all of this away. */
+enum { WO_M_DISC = 0, WO_M_ROOT = 1, WO_M_PLANE = 2, WO_M_NEAREST = 3, WO_M_SHADOW_T = 4, WO_M_CAST = 5, WO_M_FACE = 6,
+       WO_M_TIR = 7, WO_M_SITES = 8 };
+#ifdef WO_MARGINS
+static __thread float* wo_margin_row = 0;
+static inline void wo_margin(int site, float a, float b) {
+    if (!wo_margin_row) return;
+    float den = fabsf(a) + fabsf(b);
+    float m = den > 0.0f ? fabsf(a - b) / den : 1.0f;
+    if (m == m && m < wo_margin_row[site]) wo_margin_row[site] = m;
+}
+#define WO_MARGIN(site, a, b) wo_margin(site, a, b)
+#else
+#define WO_MARGIN(site, a, b) ((void)0)
+#endif
+
 /* ---- wire structs (types.cl:4-59; host mirrors cpu_obj.h:10-48) -------- */
 typedef struct {
     float rgb[4];
@@ -89,6 +111,7 @@ static inline int f2i(float f, wo_counters* c) {
     if (f != f) { if (c) c->int_cast_oor++; return 0; }
     if (f >= 2147483648.0f) { if (c) c->int_cast_oor++; return 2147483647; }
     if (f < -2147483648.0f) { if (c) c->int_cast_oor++; return (-2147483647 - 1); }
+    WO_MARGIN(WO_M_CAST, f + fminf(f - floorf(f), ceilf(f) - f), f);
     return (int)f;
 }
 
@@ -118,6 +141,7 @@ static void map_to_cube(v3 dir, uint32_t face_size, int32_t uv[2], wo_counters* 
     if (!yp && ay >= ax && ay >= az) { max_axis = ay; uc = x;  vc = z;  shift_u = face_size; }
     if (zp && az >= ax && az >= ay)  { max_axis = az; uc = x;  vc = y;  shift_u = face_size; shift_v = face_size * 1; }
     if (!zp && az >= ax && az >= ay) { max_axis = az; uc = -x; vc = y;  shift_u = face_size * 3; shift_v = face_size * 1; }
+    WO_MARGIN(WO_M_FACE, ax, ay); WO_MARGIN(WO_M_FACE, ax, az); WO_MARGIN(WO_M_FACE, ay, az);
     float fu = 0.5f * (uc / max_axis + 1.0f);
     float fv = 0.5f * (vc / max_axis + 1.0f);
     uv[0] = f2i((float)shift_u + fu * (float)face_size, c);
@@ -145,6 +169,7 @@ static inline v3 refract(float n1, float n2, v3 i, v3 nrm) {
     float n = n1 / n2;
     float cosI = -dot(nrm, i);
     float sinT2 = n * n * (1.0f - cosI * cosI);
+    WO_MARGIN(WO_M_TIR, sinT2, 1.0f);
     if (sinT2 > 1.0f) return V(NAN, NAN, NAN);
     float cosT = sqrtf(1.0f - sinT2);
     return add(muls(i, n), muls(nrm, n * cosI - cosT));
@@ -181,8 +206,10 @@ static inline int intersect_sphere(const ray_t* r, v3 center, float radius, floa
     float b = dot(muls(v, 2), r->dir);
     float c = dot(v, v) - radius * radius;
     float D = b * b - 4 * a * c;
+    WO_MARGIN(WO_M_DISC, b * b, 4 * a * c);
     if (D < 0) return 0;
     D = sqrtf(D);
+    WO_MARGIN(WO_M_ROOT, -b, D);
     float t2 = ((-b - D) / (2 * a) < 0) ? (-b + D) / (2 * a) : (-b - D) / (2 * a);
     if (t2 <= 0) return 0;
     *t = t2;
@@ -195,6 +222,8 @@ static inline int intersect_plane(const ray_t* r, v3 n, v3 p0, float* t, wo_coun
     float b = dot(r->dir, n);
     if (b == 0) return 0;
     float t2 = dot(sub(p0, r->origin), n) / b;
+    WO_MARGIN(WO_M_PLANE, dot(p0, n), dot(r->origin, n));
+    WO_MARGIN(WO_M_PLANE, b + 1.0f, 1.0f);
     if (t2 <= 0) return 0;
     *t = t2;
     return 1;
@@ -271,6 +300,7 @@ static int find_solid(const ray_t* r, const wo_scene* sc, v3* point, v3* normal,
     for (uint32_t i = 0; i < sc->ns; i++) {
         float _t;
         int hit = intersect_sphere(r, ld3(S[i].origin), S[i].radius, &_t, cnt);
+        if (hit && t < INFINITY) WO_MARGIN(WO_M_NEAREST, _t, t);
         if (!hit || _t >= t) continue; /* strict: ties keep the earlier primitive */
         t = _t;
         ip = add(r->origin, muls(r->dir, t));
@@ -282,6 +312,7 @@ static int find_solid(const ray_t* r, const wo_scene* sc, v3* point, v3* normal,
     for (uint32_t i = 0; i < sc->np; i++) {
         float _t;
         int hit = intersect_plane(r, ld3(P[i].normal), ld3(P[i].point), &_t, cnt);
+        if (hit && t < INFINITY) WO_MARGIN(WO_M_NEAREST, _t, t);
         if (!hit || _t >= t) continue;
         t = _t;
         ip = add(r->origin, muls(r->dir, t));
@@ -315,6 +346,7 @@ static float shadow_path(v3 to, v3 from, const wo_scene* sc, wo_counters* cnt) {
     for (uint32_t i = 0; i < sc->ns; i++) {
         float _t;
         int hit = intersect_sphere(&r, ld3(S[i].origin), S[i].radius, &_t, cnt);
+        if (hit) WO_MARGIN(WO_M_SHADOW_T, _t, t);
         if (!hit || _t >= t) continue;
         if (S[i].material.transperent) { opacity *= TRANSPARENT_THROUGH; continue; }
         return 0.0f;
@@ -322,6 +354,7 @@ static float shadow_path(v3 to, v3 from, const wo_scene* sc, wo_counters* cnt) {
     for (uint32_t i = 0; i < sc->np; i++) {
         float _t;
         int hit = intersect_plane(&r, ld3(P[i].normal), ld3(P[i].point), &_t, cnt);
+        if (hit) WO_MARGIN(WO_M_SHADOW_T, _t, t);
         if (!hit || _t >= t) continue;
         return 0.0f;
     }
@@ -509,6 +542,26 @@ int wo_render(const wo_camera* cam, const wo_scene* sc, int depth, uint64_t id_b
               uint64_t id_end, uint32_t* out, float* out_rgb, wo_counters* counters, int threads) {
     return render_impl(cam, NULL, sc, depth, id_begin, id_end, out, out_rgb, counters, threads);
 }
+
+#ifdef WO_MARGINS
+/* wo_render plus margins[WO_M_SITES * n]: per pixel the smallest relative margin seen at each site class (1 = none). */
+int wo_render_margins(const wo_camera* cam, const wo_scene* sc, int depth, uint64_t id_begin, uint64_t id_end,
+                      uint32_t* out, float* margins) {
+    if (depth < 1 || depth > WO_MAX_DEPTH || id_end < id_begin) return -1;
+    int64_t n = (int64_t)(id_end - id_begin);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+    for (int64_t k = 0; k < n; k++) {
+        float* row = margins + WO_M_SITES * (size_t)k;
+        for (int s = 0; s < WO_M_SITES; s++) row[s] = 1.0f;
+        wo_margin_row = row;
+        out[k] = trace_pixel((uint32_t)(id_begin + (uint64_t)k), raygen_one(cam, id_begin + (uint64_t)k), sc, depth, NULL, NULL);
+        wo_margin_row = 0;
+    }
+    return 0;
+}
+#endif
 
 int wo_trace_rays(const float* rays16, const wo_scene* sc, int depth, uint64_t id_begin,
                   uint64_t id_end, uint32_t* out, float* out_rgb, wo_counters* counters,

@@ -56,6 +56,19 @@ def golden_frames():
 
 
 @pytest.fixture(scope="session")
+def golden_masks():
+    return dict(np.load(os.path.join(GOLDEN, "masks.npz")))
+
+
+def frame_mask(golden_masks, key, n, parts=("fma", "jitter", "margin")):
+    """Union of the named discontinuity masks of frame `key` as a boolean array of n pixels (oracle/gen_golden.py)."""
+    m = np.zeros(n, bool)
+    for name in parts:
+        m |= np.unpackbits(golden_masks[f"{key}_{name}"])[:n].astype(bool)
+    return m
+
+
+@pytest.fixture(scope="session")
 def golden_vectors():
     return dict(np.load(os.path.join(GOLDEN, "vectors.npz")))
 

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import CAM, REFERENCE_ROOT, ROOT
+from conftest import GOLDEN, CAM, REFERENCE_ROOT, ROOT
 from example_gui_opencl_raytracer_amd import api, scene as S, textures as T
 from example_gui_opencl_raytracer_amd.renderer import strip_rows
 
@@ -103,6 +103,19 @@ def test_camera_matches_oracle_bit_for_bit(oracle, cam):
     assert bytes(mine) == bytes(ref)
 
 
+def test_camera_matches_the_references_own_rgen_perspective():
+    """tests/golden/camera.npz holds what the reference's OWN src/cpu_ray.c (rinit_camera + rgen_perspective,
+    cpu_ray.c:24-35, 42-106; compiled into oracle/_ref/libref_cpu_ray.so by oracle/gen_golden.py) returns for twelve
+    cameras: the product's clw_host_perspective must give the same bytes (H1 pinned against the reference itself)."""
+    g = np.load(os.path.join(GOLDEN, "camera.npz"))
+    assert len(g["inputs"]) >= 5
+    for row, want in zip(g["inputs"], g["outputs"]):
+        o, l, fov, focal, w, h = row[0:3], row[3:6], float(row[6]), float(row[7]), int(row[8]), int(row[9])
+        cam = api.perspective(tuple(o), tuple(l), fov, focal, w, h)
+        got = np.array(list(cam.im_corner) + list(cam.origin) + list(cam.up) + list(cam.right) + [cam.w_factor, cam.h_factor], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (row, got, want)
+
+
 def test_camera_rejections():
     for bad in (dict(look=(0, 1, 0), fov=90.0), dict(look=(0, 0, 1), fov=180.0), dict(look=(0, 0, 1), fov=0.0)):
         with pytest.raises(ValueError):
@@ -140,6 +153,27 @@ def test_png_reader_accepts_filtered_files_and_rejects_non_rgb8(tmp_path):
         api.read_png(str(tmp_path / "junk.png"))
     with pytest.raises(ValueError, match=r"\(1\)"):
         api.read_png(str(tmp_path / "missing.png"))
+
+
+def test_png_reader_rejects_sizes_that_overflow(tmp_path):
+    """A crafted IHDR whose width x height products wrap size_t must be refused before anything is allocated."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+    for (w, h) in ((0xFFFFFFFF, 0xFFFFFFFF), (0x80000000, 1), (0x7FFFFFFF, 0x7FFFFFFF), (1, 0x80000001), (0x40000000, 0x40000000)):
+        ihdr = struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        p = tmp_path / f"big_{w}_{h}.png"
+        p.write_bytes(png)
+        with pytest.raises(ValueError):
+            api.read_png(str(p))
+    # a chunk length beyond 2^31 (it would be truncated by the (long) cast of the skip) is refused as well
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) + struct.pack(">I", 0xFFFFFFF0) + b"tEXt"
+    (tmp_path / "len.png").write_bytes(png)
+    with pytest.raises(ValueError):
+        api.read_png(str(tmp_path / "len.png"))
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="reference tree absent")

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import CAM
 
-FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)]
+FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4), (640, 480, 1)]   # the last one is BASELINE config C1
 
 
 @pytest.mark.parametrize("w,h,depth", FRAMES)
@@ -20,6 +20,37 @@ def test_frames_bit_exact(oracle, demo_scene, tex, sky, golden_frames, w, h, dep
     want = golden_frames[f"render_map_{w}x{h}_d{depth}"]
     assert np.array_equal(got, want)
     assert cnt.oob_reads == 0 and cnt.int_cast_oor == 0    # no undefined-behaviour inputs on golden scenes
+
+
+def test_masks_belong_to_the_reference_frames(oracle, demo_scene, tex, sky, golden_frames, golden_masks):
+    """tests/golden/masks.npz: every mask set carries the CRC of the reference frame it was derived from; the oracle's
+    frame must have that CRC (so the 1280x720 frame, too big to commit as pixels, is pinned on the GPU box as well),
+    and the masks must be what they claim: small."""
+    import zlib
+    for (w, h, depth) in FRAMES + [(1280, 720, 4)]:
+        key = f"render_map_{w}x{h}_d{depth}"
+        cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+        got, _, _ = oracle.render(cam, demo_scene, tex, sky, depth)
+        assert zlib.crc32(got.tobytes()) == int(golden_masks[key + "_crc32"][0])
+        if key in golden_frames:
+            assert np.array_equal(got, golden_frames[key])
+        un = np.zeros(w * h, bool)
+        for name in ("fma", "jitter", "margin"):
+            m = np.unpackbits(golden_masks[f"{key}_{name}"])[: w * h].astype(bool)
+            assert m.shape == (w * h,)
+            un |= m
+        assert 0.0 < un.mean() < (0.10 if w >= 640 else 0.20), (key, un.mean())
+
+
+def test_camera_restatement_matches_the_references_own_rgen_perspective(oracle):
+    """wo_perspective (the oracle's camera) against the bytes the reference's src/cpu_ray.c produced (camera.npz)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "camera.npz"))
+    for row, want in zip(g["inputs"], g["outputs"]):
+        cam = oracle.camera(tuple(row[0:3]), tuple(row[3:6]), float(row[6]), float(row[7]), int(row[8]), int(row[9]))
+        got = np.array(list(cam.im_corner) + list(cam.origin) + list(cam.up) + list(cam.right) + [cam.w_factor, cam.h_factor], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_frame_is_thread_count_independent(oracle, demo_scene, tex, sky, golden_frames):

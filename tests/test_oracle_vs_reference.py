@@ -54,6 +54,25 @@ def test_textures_off_and_all_layers(oracle, reference, demo_scene, tex, sky):
         assert (cnt.texel_fetches == 0) == (tid < 0)
 
 
+def test_committed_fixtures_are_what_the_reference_produces_now(oracle, reference, demo_scene, tex, sky, golden_masks):
+    """Regenerates, from the reference builds in oracle/_ref, the camera fixtures and one mask set, and compares them
+    with the committed files (so the fixtures cannot drift from oracle/gen_golden.py)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import gen_golden as G
+    from oracle.oracle_py import REF_FMA_SO, RefCamera, Reference
+    if not (RefCamera.available() and os.path.exists(REF_FMA_SO)):
+        pytest.skip("oracle/_ref camera / fma builds absent")
+    g = np.load(os.path.join(GOLDEN, "camera.npz"))
+    rc = RefCamera()
+    for (o, l, fov, focal, w, h), want in zip(G.CAMERAS, g["outputs"]):
+        assert np.array_equal(rc.perspective(o, l, fov, focal, w, h).view(np.uint32), want.view(np.uint32))
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 320, 240)
+    _, mk = G.make_masks(reference, Reference(REF_FMA_SO), oracle, cam, demo_scene, tex, sky, 4)
+    for name, m in mk.items():
+        assert np.array_equal(np.packbits(m), golden_masks[f"render_map_320x240_d4_{name}"]), name
+
+
 def test_raygen_bit_exact(oracle, reference):
     cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 200, 150)
     assert np.array_equal(oracle.raygen(cam).view(np.uint32), reference.raygen(cam).view(np.uint32))
