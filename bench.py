@@ -3,7 +3,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong | --config c5]
 
 Workload (BASELINE.json configs[1], "C2"): the reference's demo scene (scenes/render.map,
 regenerated from scene_dump.c's values), camera of raypng.c:17-21, 1920x1080, depth 4, textures
@@ -12,14 +12,21 @@ cannot travel to the GPU box).  One step = one frame through the reference's cal
 (`cl_wrap_output(raygen)` + `cl_wrap_output(raytracer)`, raypng.c:86-89) with every input
 resident in HBM and the framebuffer left in HBM.
 
-N > 1 (weak scaling): every GPU keeps a 1920x1080 share of ONE 1920 x (1080*N) frame -- rank r
-owns every N-th 8-row band (interleaved so the shares cost the same) with GLOBAL work-item ids,
-so the assembled frame is bit-identical to a single-GPU render.  No data-path collective while
-tracing; each step ends with one gather of the bands (packed to RGB888) to rank 0 over RCCL/xGMI on
-a side stream, double-buffered so it overlaps the next frame's trace.
+Sharding for N > 1 (one process per GPU, no data-path collective while tracing, GLOBAL work-item ids, so the
+assembled frame is bit-identical to a single-GPU render):
+  default            weak scaling: every GPU keeps a 1920x1080 share of ONE 1920 x (1080*N) frame -- rank r owns
+                     every N-th 8-row band (interleaved so the shares cost the same);
+  --scaling strong   the FIXED 1920x1080 frame cut into N contiguous row strips (north_star's row-strip split);
+  --config c5        BASELINE config 5: 8192x8192, depth 4, N row strips, the single PNG written by rank 0 after
+                     the timed region (its time is reported separately).
+Each step ends with one gather of the rows (packed to RGB888) into rank 0's frame buffer over xGMI: every rank stores
+its share straight into rank 0's peer-mapped buffer (one device-to-device copy per rank; `distributed.FrameGatherer`),
+on a side stream and double-buffered so it overlaps the next frame's trace.
 
-rays = path segments + shadow rays, counted by the counting build of the kernel
-outside the timed region.  rank 0 prints ONE JSON line.
+rays = path segments + shadow rays, counted by the counting build of the kernel outside the timed
+region; `rays_traced` leaves out the shadow rays of zero-coefficient surfaces, which the kernel draws but does not
+trace.  rank 0 prints ONE JSON line; at N = 1 it also carries the strict (bit-exact parity) build timed on the same
+workload, the kernel's roofline figures and the CPU baseline (the oracle on the host cores; C2 and C1).
 """
 from __future__ import annotations
 
@@ -39,70 +46,62 @@ if ROOT not in sys.path:
 
 import example_gui_opencl_raytracer_amd as pkg  # noqa: E402
 from example_gui_opencl_raytracer_amd import distributed as D, scene, textures  # noqa: E402
-from example_gui_opencl_raytracer_amd.renderer import Renderer  # noqa: E402
+from example_gui_opencl_raytracer_amd.renderer import Renderer, strip_rows  # noqa: E402
 
-W, H_PER_GPU, DEPTH = 1920, 1080, 4
+DEPTH = 4
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak fp32 vector
-VALU_SLOT_NS = 1.04             # measured: one plain wave64 VALU instruction per SIMD (tools/ubench/valu_rates.hip)
-TRANS_WEIGHT = 3.1              # measured: a transcendental occupies 3.1 such slots
+VALU_CYCLES, TRANS_CYCLES = 2.0, 8.0   # MI355X_MICROARCH.md cycle constants: v_fma_f32 wave64 2 cycles per SIMD, transcendentals 8
+CLOCK_GHZ, SIMDS = 2.4, 1024
 TIMING_EVERY = 8                # hipEvents around every 8th trace launch of a frame slot (an event record between two
                                 # kernels delays the second: 5 us per frame if every launch is timed)
 # fp32 operations of the reference's expression trees (DESIGN.md section "flop model")
 FLOP = dict(sphere_test=34, plane_test=14, shadow_ray=40, light_shade=94, shaded_hit=73, sky=20, texel=25)
 
 
-def profiled_traffic():
-    """HBM bytes per trace launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_rocprof_summary.md: FETCH_SIZE and WRITE_SIZE, KiB per dispatch, separate passes).  The
-    guide's x2 FETCH_SIZE correction is for wide coalesced streams; this kernel's reads are 4-byte texel
-    gathers, so the raw counter is used (uncalibrated for that width)."""
+def profiled(counter):
+    """Per-launch mean of a rocprofv3 PMC counter for the C2 trace kernel, from the newest committed summary of this
+    same command (profiles/*_rocprof_summary.md, lines `COUNTER,value,dispatches`) -> (value, file) or None."""
     import glob
     import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
-        txt = open(f).read()
-        fe, wr = re.search(r"^FETCH_SIZE,([0-9.]+)", txt, re.M), re.search(r"^WRITE_SIZE,([0-9.]+)", txt, re.M)
-        if fe and wr:
-            best = (int((float(fe.group(1)) + float(wr.group(1))) * 1024), os.path.basename(f))
-    return best
-
-
-def profiled_valu_instructions():
-    """(SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32) per trace launch (wave-level instructions) from the committed PMC passes."""
-    import glob
-    import re
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
-        txt = open(f).read()
-        m = re.search(r"^SQ_INSTS_VALU,([0-9.]+)", txt, re.M)
-        t = re.search(r"^SQ_INSTS_VALU_TRANS_F32,([0-9.]+)", txt, re.M)
+        m = re.search(rf"^{counter},([0-9.]+)", open(f).read(), re.M)
         if m:
-            best = (float(m.group(1)), float(t.group(1)) if t else 0.0, os.path.basename(f))
+            best = (float(m.group(1)), os.path.basename(f))
     return best
 
 
-def cpu_baseline(sc, tex, sky):
-    """The oracle (plain-C restatement, OpenMP over pixels) on this box's host cores: ONE full C2
-    frame per run, 3 runs.  Returns (dict for the JSON line, oracle counters of the frame)."""
+def cpu_baseline(sc, tex, sky, W, H):
+    """The oracle (plain-C restatement, OpenMP over pixels) on this box's host cores: ONE full C2 frame per run,
+    3 runs, plus 1/8 frame on one thread; and BASELINE config C1 (render.map 640x480 depth 1, the reference's own
+    CPU-runnable case) the same way.  Returns (dict for the JSON line, oracle counters of the C2 frame)."""
     from oracle.oracle_py import Oracle
     o = Oracle()
-    cam = o.camera(pkg.CAMERA_RAYPNG["origin"], pkg.CAMERA_RAYPNG["look"], 90.0, 1.0, W, H_PER_GPU)
     threads = o.num_threads()
-    times, cnt = [], None
-    for _ in range(3):
+
+    def run(w, h, depth, reps):
+        cam = o.camera(pkg.CAMERA_RAYPNG["origin"], pkg.CAMERA_RAYPNG["look"], 90.0, 1.0, w, h)
+        times, cnt = [], None
+        for _ in range(reps):
+            t = time.perf_counter()
+            _, _, cnt = o.render(cam, sc, tex, sky, depth, threads=0)
+            times.append(time.perf_counter() - t)
+        rows = max(h // 8, 1)
         t = time.perf_counter()
-        _, _, cnt = o.render(cam, sc, tex, sky, DEPTH, threads=0)
-        times.append(time.perf_counter() - t)
-    rows = H_PER_GPU // 8
-    t = time.perf_counter()
-    _, _, c1 = o.render(cam, sc, tex, sky, DEPTH, id_begin=0, id_end=rows * W * 1, threads=1)
-    t1 = time.perf_counter() - t
-    med = statistics.median(times)
-    return dict(value=round(cnt.rays / med / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
-                sample=f"3 x one full frame 1920x1080 depth 4 (median {med:.3f} s, {cnt.rays} rays)",
-                single_thread_Mrays_s=round(c1.rays / t1 / 1e6, 3),
-                frames_per_s=round(1.0 / med, 3)), cnt
+        _, _, c1 = o.render(cam, sc, tex, sky, depth, id_begin=0, id_end=rows * w, threads=1)
+        t1 = time.perf_counter() - t
+        return statistics.median(times), cnt, c1.rays / t1 / 1e6
+
+    med, cnt, st = run(W, H, DEPTH, 3)
+    base = dict(value=round(cnt.rays / med / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
+                sample=f"3 x one full frame {W}x{H} depth {DEPTH} (median {med:.3f} s, {cnt.rays} rays)",
+                single_thread_Mrays_s=round(st, 3), frames_per_s=round(1.0 / med, 3))
+    m1, c1, st1 = run(640, 480, 1, 5)
+    base["c1"] = dict(workload="C1: scenes/render.map 640x480 depth 1 (BASELINE configs[0], CPU path)", value=round(c1.rays / m1 / 1e6, 3),
+                      unit="Mrays/s", cores=threads, single_thread_Mrays_s=round(st1, 3), frames_per_s=round(1.0 / m1, 2),
+                      rays_per_pixel=round(c1.rays / (640 * 480), 4), sample=f"5 x one full frame (median {m1 * 1e3:.2f} ms)")
+    return base, cnt
 
 
 def main():
@@ -110,8 +109,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--strict", type=int, default=0, help="1: strict arithmetic build (parity build)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 1920x1080 per GPU of a taller frame (default); strong: the fixed 1920x1080 frame in row strips")
+    ap.add_argument("--config", choices=("c2", "c5"), default="c2", help="c5: 8192x8192 depth 4 in row strips + the single PNG")
+    ap.add_argument("--strict", type=int, default=0, help="1: the headline itself runs the strict arithmetic build")
+    ap.add_argument("--transport", choices=("auto", "peer", "gather"), default="auto", help="how shares reach rank 0 (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip timing the strict build next to the fast headline")
     ap.add_argument("--own-streams", action="store_true",
                     help="experiment: each frame slot launches on its own stream, so consecutive frames overlap")
     ap.add_argument("--rehearse", action="store_true",
@@ -133,101 +137,174 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local_rank)
 
+    # ---- the frame and this rank's rows
+    c5 = args.config == "c5"
+    strong = c5 or args.scaling == "strong"
+    if c5:
+        W, H = 8192, 8192
+    elif strong:
+        W, H = 1920, 1080
+    else:
+        W, H = 1920, 1080 * world
+    if strong:
+        first_row, rows = strip_rows(H, world, rank)
+        shard = dict(first_row=first_row, rows=rows) if world > 1 else {}
+        layout = "strips"
+    else:
+        rows = H // world
+        shard = dict(bands=(world, rank)) if world > 1 else {}
+        layout = "bands"
+    px_rank = W * rows
+
     sc = scene.render_map_scene()
     tex, sky = textures.texture_layers(), textures.skybox_cross(4096)
-    H = H_PER_GPU * world
-    px_rank = W * H_PER_GPU
     # every launch of this rank goes to ONE explicit HIP stream that torch also treats as current, so the
     # shim's hipEvents, torch's collectives and the synchronisation around the timed region agree
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
     # two frame slots: the gather of frame k overlaps the trace of frame k+1
-    fbs = [torch.zeros(px_rank, dtype=torch.int32, device=dev) for _ in range(2)]
-    rr = []
-    for fb in fbs:
-        r = Renderer(sc, tex, sky, W, H, depth=DEPTH, strict=bool(args.strict),
-                     bands=(world, rank) if world > 1 else None, framebuffer_ptr=fb.data_ptr())
-        if not args.own_streams:
-            r.w.set_stream(stream.cuda_stream)
-        r.look(**pkg.CAMERA_RAYPNG)
-        r.w.set_async(True)
-        rr.append(r)
-    gat = D.BandGatherer(W, H, rank, world, dev, staged_on_cpu=args.rehearse and not args.rehearse_device_tensors)
+    fbs = [torch.zeros(max(px_rank, 1), dtype=torch.int32, device=dev) for _ in range(2)]
 
-    def step(k):
+    def make_renderers(strict):
+        out = []
+        for fb in fbs:
+            r = Renderer(sc, tex, sky, W, H, depth=DEPTH, strict=strict, framebuffer_ptr=fb.data_ptr(), **shard)
+            if not args.own_streams:
+                r.w.set_stream(stream.cuda_stream)
+            r.look(**pkg.CAMERA_RAYPNG)
+            r.w.set_async(True)
+            out.append(r)
+        return out
+
+    rr = make_renderers(bool(args.strict))
+    gat = D.FrameGatherer(W, H, rank, world, dev, layout=layout, transport=args.transport,
+                          staged_on_cpu=args.rehearse and not args.rehearse_device_tensors)
+
+    def step(k, rs=None):
         s = k & 1
         gat.before_render(s)                       # frame k-2's pixels have been packed for their gather
-        rr[s].render(readback=False)               # raygen latch + trace launch (async, torch's stream)
+        (rs or rr)[s].render(readback=False)       # raygen latch + trace launch (async, torch's stream)
         if world > 1:
             if args.rehearse:
                 torch.cuda.current_stream().synchronize()
-            gat.submit(s, fbs[s])                  # pack to RGB888 + gather on the side stream
-
-    def drain():
-        gat.drain()
+            gat.submit(s, fbs[s][:px_rank])        # pack to RGB888 + store into rank 0's buffer on the side stream
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
+
+    def timed(n, rs=None):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            step(k, rs)
+        gat.drain()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def kernel_ms(rs):
+        launches, kms = 0, 0.0
+        for r in rs:
+            n, ms = r.w.timing_get(1)
+            launches += n
+            kms += ms
+        return kms / max(launches, 1), launches
+
+    def arm_timing(rs):
+        for r in rs:
+            r.w.timing_reset()
+            r.w.set_timing_every(TIMING_EVERY)
 
     # ---- ray count of one frame share (counting build, outside the timed region)
     rr[0].w.enable_counters(1)
     rr[0].render(readback=False)
     cnt = rr[0].w.read_counters()
     rr[0].w.enable_counters(0)
-    rays_rank = cnt["segments"] + cnt["shadow_rays"]
-    tot = torch.tensor([rays_rank, cnt["texel_fetches"] + cnt["sky_fetches"], cnt["lane_iters"], cnt["wave_iters_x64"]],
-                       dtype=torch.float64, device=dev)
+    tot = torch.tensor([cnt["segments"] + cnt["shadow_rays"], cnt["texel_fetches"] + cnt["sky_fetches"], cnt["lane_iters"],
+                        cnt["wave_iters_x64"], cnt["segments"] + cnt["shadow_rays_traced"]], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tot)
-    rays_step, fetch_step = int(tot[0].item()), int(tot[1].item())
+    rays_step, rays_traced_step = int(tot[0].item()), int(tot[4].item())
 
     for k in range(args.warmup):
         step(k)
-    drain()
-    for r in rr:
-        r.w.timing_reset()
-        r.w.set_timing_every(TIMING_EVERY)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    drain()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+    gat.drain()
+    arm_timing(rr)
+    elapsed = timed(args.steps)
+    k_ms, launches = kernel_ms(rr)
 
-    launches, kms = 0, 0.0
-    for r in rr:
-        n, ms = r.w.timing_get(1)
-        launches += n
-        kms += ms
-    kernel_ms = kms / max(launches, 1)
+    if rank == 0 and args.dump_png and not c5:
+        from example_gui_opencl_raytracer_amd import api
+        s = (args.steps - 1) & 1
+        full = fbs[s][:px_rank].cpu().numpy().view(np.uint32) if world == 1 else gat.assemble(s).cpu().numpy().view(np.uint32)
+        api.write_png(args.dump_png, full, W, H)
 
-    # PCIe-inclusive frame rate (what rayinteractive's loop sees: launch + wait + blocking read-back)
+    # ---- C5: the single PNG, written by rank 0 from the gathered frame; timed separately
+    png = None
+    if c5 and rank == 0:
+        from example_gui_opencl_raytracer_amd import api
+        s = (args.steps - 1) & 1
+        path = args.dump_png or os.path.join(ROOT, "gpurun_out", "c5.png")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        t = time.perf_counter()
+        full = fbs[s][:px_rank].cpu().numpy().view(np.uint32) if world == 1 else gat.assemble(s).cpu().numpy().view(np.uint32)
+        t_host = time.perf_counter() - t
+        t = time.perf_counter()
+        api.write_png(path, full, W, H)
+        t_png = time.perf_counter() - t
+        png = dict(path=os.path.relpath(path, ROOT), bytes=os.path.getsize(path), assemble_and_readback_s=round(t_host, 4),
+                   write_s=round(t_png, 3), note="outside the timed region: deflate level 1 of the 192 MB RGB image on one host core")
+    barrier()
+
+    # ---- N = 1 extras: PCIe-inclusive frame rates, a moving camera, the strict build on the same workload
     host = np.empty(px_rank, np.uint32)
-    rb = []
-    if rank == 0:
+    rb, moving, strict_leg = [], None, None
+    if rank == 0 and world == 1:
         rr[0].w.set_async(False)
         for _ in range(5):
             tt = time.perf_counter()
             rr[0].w.output(px_rank, 0, 0, 0, 0, None)
             rr[0].w.output(px_rank, host.nbytes, 1, 1, 10, host)
             rb.append(time.perf_counter() - tt)
-
-    if rank == 0 and args.dump_png:
-        from example_gui_opencl_raytracer_amd import api
-        if world == 1:
-            full = fbs[(args.steps - 1) & 1].cpu().numpy().view(np.uint32)
-        else:
-            full = gat.assemble((args.steps - 1) & 1).cpu().numpy().view(np.uint32)
-        api.write_png(args.dump_png, full, W, H)
+        rr[0].w.set_async(True)
+        if not c5:
+            # the interactive loop's shape (rayinteractive.c:183-197): the camera turns a little EVERY frame, so every
+            # frame's tile costs are re-sorted (on the shim's side stream, behind the frame)
+            n = min(args.steps, 200)
+            looks = [(0.2 + 0.002 * np.sin(0.1 * i), 0.0005 * i, 1.0) for i in range(n + 8)]
+            for i in range(8):
+                rr[i & 1].look(pkg.CAMERA_RAYPNG["origin"], looks[i])
+                rr[i & 1].render(readback=False)
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            for i in range(n):
+                rr[i & 1].look(pkg.CAMERA_RAYPNG["origin"], looks[8 + i])
+                rr[i & 1].render(readback=False)
+            torch.cuda.synchronize()
+            moving = dict(frames_per_s=round(n / (time.perf_counter() - tt), 1), frames=n,
+                          note="camera re-set before every frame (kernel-only, no read-back); tile order re-sorted every frame off the critical path")
+            for r in rr:
+                r.look(**pkg.CAMERA_RAYPNG)
+        if not args.strict and not args.no_strict_leg and not c5:
+            rs = make_renderers(True)
+            n = max(min(args.steps, 100), 2)
+            for k in range(6):
+                step(k, rs)
+            torch.cuda.synchronize()
+            arm_timing(rs)
+            el = timed(n, rs)
+            ks, _ = kernel_ms(rs)
+            strict_leg = dict(ms_per_step=round(el / n * 1e3, 4), value=round(rays_step * n / el / 1e6, 1), unit="Mrays/s",
+                              steps=n, trace_kernel_ms=round(ks, 4), note="the bit-exact parity build (clw_ext_set_strict) on the same workload")
+            for r in rs:
+                r.release()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -235,45 +312,61 @@ def main():
         # algorithmic HBM bytes of ONE trace launch on this rank: the 4-byte packed pixel per
         # work-item + one 4-byte texel per texture / skybox fetch + the prepared geometry once
         bytes_launch = 4 * px_rank + 4 * (cnt["texel_fetches"] + cnt["sky_fetches"]) + 16 * (4 + 2 * 2 + 2 * 3)
-        ach = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = profiled_traffic() if world == 1 else None
+        ach = bytes_launch / (k_ms * 1e-3) / 1e9
+        single_c2 = world == 1 and not c5
+        fe, wr = (profiled("FETCH_SIZE"), profiled("WRITE_SIZE")) if single_c2 else (None, None)
+        traffic = int((fe[0] + wr[0]) * 1024) if fe and wr else None
+        workload = ("C5: scenes/render.map 8192x8192 depth 4" if c5 else "C2: scenes/render.map (regenerated), camera raypng.c:17-21, 1920x1080"
+                    + (" per GPU" if not strong else "") + ", depth 4, 2 soft-shadow samples, 4x256^2 textures + 4096x3072 skybox (procedural)")
         line = {
-            "metric": "Mrays/s (path segments + shadow rays) at 1920x1080 depth 4 per GPU",
+            "metric": "Mrays/s (path segments + shadow rays) at 1920x1080 depth 4, aggregate over n_gpus" if not c5 else
+                      "Mrays/s (path segments + shadow rays) at 8192x8192 depth 4, aggregate over n_gpus",
             "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: scenes/render.map (regenerated), camera raypng.c:17-21, 1920x1080 per GPU, "
-                                   "depth 4, 2 soft-shadow samples, 4x256^2 textures + 4096x3072 skybox (procedural)",
-                       "frame": f"{W}x{H}", "sharding": "single GPU" if world == 1 else f"interleaved 8-row bands x{world} + gather to rank 0",
+            "config": {"workload": workload, "frame": f"{W}x{H}",
+                       "sharding": "single GPU" if world == 1 else
+                                   (f"{world} contiguous row strips" if strong else f"interleaved 8-row bands x{world}") +
+                                   f" + one gather of RGB888 rows into rank 0 per frame ({gat.transport})",
                        "arithmetic": "strict" if args.strict else "fast", "rays_per_pixel": round(rays_step / (W * H), 4)},
+            "value_per_gpu": round(value / world, 1),
+            "rays": rays_step, "rays_traced": rays_traced_step,
+            "value_traced": round(rays_traced_step * args.steps / elapsed / 1e6, 1),
             "frames_per_s": round(args.steps / elapsed, 1),
             "frames_per_s_with_readback": round(1.0 / statistics.median(rb), 1) if rb else None,
-            "trace_kernel_ms": round(kernel_ms, 4), "trace_launches_timed": launches,
+            "trace_kernel_ms": round(k_ms, 4), "trace_launches_timed": launches,
             "lane_utilisation": round(float(tot[2].item() / max(tot[3].item(), 1.0)), 4),
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic[0] if traffic else None,
-                         "algorithmic_bytes": bytes_launch, "traffic_source": traffic[1] if traffic else None,
+                         "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "algorithmic_bytes": bytes_launch, "traffic_source": fe[1] if traffic else None,
                          "note": "algorithmic bytes/launch = 4 B x pixels + 4 B x texel fetches + geometry; the path is "
-                                 "VALU-bound (723-byte scene), see roofline_valu"},
+                                 "VALU-bound (723-byte scene), see roofline_valu / roofline_valu_issue"},
         }
-        vi = profiled_valu_instructions() if world == 1 else None
+        if strict_leg:
+            line["strict"] = strict_leg
+        if moving:
+            line["moving_camera"] = moving
+        if png:
+            line["png"] = png
+        vi, vt = (profiled("SQ_INSTS_VALU"), profiled("SQ_INSTS_VALU_TRANS_F32")) if single_c2 else (None, None)
         if vi:
-            # issue slots: a plain wave64 VALU instruction takes 1.04 ns of a SIMD, a transcendental (v_rcp/rsq/sqrt/
-            # sin/cos/log/exp) 3.1x that (tools/ubench/valu_rates.hip on this chip, profiles/*_valu_rates.txt); 1 024 SIMDs
-            slots = vi[0] + (TRANS_WEIGHT - 1.0) * vi[1]
-            peak = 1024 / VALU_SLOT_NS / 1e3                     # T issue slots / s
-            got = slots / (kernel_ms * 1e-3) / 1e12
-            line["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(got, 4), "peak": round(peak, 4),
-                                           "unit": "T issue slots/s", "frac": round(got / peak, 4),
-                                           "valu_instructions_per_launch": int(vi[0]), "transcendental_per_launch": int(vi[1]),
-                                           "slot_ns": VALU_SLOT_NS, "transcendental_weight": TRANS_WEIGHT, "source": vi[2]}
-        if world == 1 and not args.no_cpu_baseline:
-            base, oc = cpu_baseline(sc, tex, sky)
+            # VALU issue bound from the guide's cycle constants: a wave64 VALU instruction occupies its SIMD for 2 cycles,
+            # a transcendental (v_rcp/rsq/sqrt/sin/cos/log/exp) for 8; 1 024 SIMDs at 2.4 GHz
+            trans = vt[0] if vt else 0.0
+            cycles = (vi[0] - trans) * VALU_CYCLES + trans * TRANS_CYCLES
+            floor_ms = cycles / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+            line["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": round(floor_ms / k_ms, 4), "peak": 1.0,
+                                           "unit": "fraction of SIMD issue cycles", "frac": round(floor_ms / k_ms, 4),
+                                           "issue_floor_ms": round(floor_ms, 4), "valu_instructions_per_launch": int(vi[0]),
+                                           "transcendental_per_launch": int(trans), "cycles_plain": VALU_CYCLES, "cycles_transcendental": TRANS_CYCLES,
+                                           "source": vi[1]}
+        if single_c2 and not args.no_cpu_baseline:
+            base, oc = cpu_baseline(sc, tex, sky, W, H)
             line["cpu_baseline"] = base
             flops = (FLOP["sphere_test"] * oc.sphere_tests + FLOP["plane_test"] * oc.plane_tests + FLOP["shadow_ray"] * oc.shadow_rays
                      + FLOP["light_shade"] * oc.shaded_hits * len(sc.lights) + FLOP["shaded_hit"] * oc.shaded_hits
                      + FLOP["sky"] * oc.sky_fetches + FLOP["texel"] * oc.texel_fetches)
-            tf = flops / (kernel_ms * 1e-3) / 1e12
+            tf = flops / (k_ms * 1e-3) / 1e12
             line["roofline_valu"] = {"bound": "valu_fp32", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(tf / VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(flops),
                                      "note": "fp32 operations of the reference's expression trees, counted by the oracle"}

@@ -99,7 +99,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.clw_ext_read_tile_costs.argtypes = [W, vp, u32]
     L.clw_ext_read_tile_costs.restype = u32
     L.clw_ext_read_counters.argtypes = [W, C.POINTER(C.c_uint64 * 8)]
-    L.clw_ext_read_counters_ex.argtypes = [W, C.POINTER(C.c_uint64 * 12), u32]
+    L.clw_ext_read_counters_ex.argtypes = [W, C.POINTER(C.c_uint64 * 32), u32]
     L.clw_ext_invalidate_scene.argtypes = [W]
     L.clw_ext_unit_scene.argtypes = [W, u32, C.c_int, vp, u32, vp, u32, u32]
     L.clw_host_perspective.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float, C.c_float, u32, u32,
@@ -266,8 +266,9 @@ class ClWrap:
     def read_counters(self):
         """Work counters of the counting build (clw_ext_read_counters_ex); `shadow_rays` counts every shadow ray the
         reference would cast, `shadow_rays_traced` leaves out the ones elided on zero-coefficient surfaces."""
-        out = (C.c_uint64 * 12)()
-        self.L.clw_ext_read_counters_ex(C.byref(self.w), C.byref(out), 12)
+        out = (C.c_uint64 * 32)()
+        self.L.clw_ext_read_counters_ex(C.byref(self.w), C.byref(out), 32)
+        self.last_raw_counters = [int(x) for x in out]
         names = ["segments", "shadow_rays", "light_probes", "sky_fetches", "texel_fetches", "pushes",
                  "lane_iters", "wave_iters_x64", "shadow_rays_traced"]
         return dict(zip(names, [int(x) for x in out]))

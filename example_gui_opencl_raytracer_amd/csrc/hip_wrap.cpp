@@ -126,6 +126,7 @@ struct Impl {
     int async = 0;
     int variant = 0;
     int counting = 0;
+    int stamps = 0;        /* CLWRAP_STAMPS=1: hand the counter block to the (diagnostic) stamp build of the kernel */
     uint64_t id_offset = 0;
     uint32_t band_stride = 1, band_phase = 0;
     float* debug_rgb = nullptr;
@@ -141,12 +142,32 @@ struct Impl {
     unsigned long long* d_counters = nullptr;
     /* cost-sorted tile dispatch: costs written by frame n order the tiles of frame n+1 */
     int sched = 1;
+    /* Double-buffered: trace k writes its tile costs into cost[k & 1]; when the camera / depth / scene changed, the
+     * order for those costs is built on a SIDE stream behind trace k (order[k & 1], 15 us, 8 workgroups) while trace
+     * k+1 already runs with the order built two frames earlier -- so a moving camera (the interactive loop of
+     * rayinteractive.c:183-197) never waits for the sort.  Any order built for the same tile grid is a valid
+     * permutation, so a stale one only costs balance, never pixels. */
     struct Sched {
-        unsigned* cost = nullptr; unsigned* order = nullptr;
+        unsigned* cost[2] = {nullptr, nullptr}; unsigned* order[2] = {nullptr, nullptr};
+        hipEvent_t built[2] = {nullptr, nullptr};    /* order[i] complete (recorded on the sched stream) */
+        bool have[2] = {false, false};                /* order[i] holds / will hold a schedule */
+        int wr = 0;                                   /* cost buffer the next trace writes */
+        hipEvent_t traced = nullptr;
         uint32_t w = 0, rows = 0;
-        bool valid = false;
-        RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0;   /* camera, depth and scene generation of `order` */
+        RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false;   /* what the newest order was built for */
+        void reset() { have[0] = have[1] = false; sig_valid = false; }
+        void free_all() {
+            for (int i = 0; i < 2; i++) {
+                if (cost[i]) (void)hipFree(cost[i]);
+                if (order[i]) (void)hipFree(order[i]);
+                if (built[i]) (void)hipEventDestroy(built[i]);
+                cost[i] = order[i] = nullptr; built[i] = nullptr;
+            }
+            if (traced) { (void)hipEventDestroy(traced); traced = nullptr; }
+            reset();
+        }
     };
+    hipStream_t sched_stream = nullptr;
     static constexpr int MAX_CHUNKS = 4;
     Sched scheds[1 + MAX_CHUNKS];   /* [0]: whole-range launches; [1 + c]: strip c of a pipelined read-back */
     /* pipelined read-back (cl_wrap_output of a large frame): strips rendered back to back, each copied to the host
@@ -468,8 +489,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         flags |= F_RAYS;
     }
     if (I->depth > SHALLOW_LEVELS + 1) flags |= F_DEEP;
-    if (I->counting) {
-        flags |= F_COUNT;
+    if (I->counting || I->stamps) {
+        if (I->counting) flags |= F_COUNT;
         if (!I->d_counters) {
             HIP_OK(hipMalloc((void**)&I->d_counters, CLW_NUM_COUNTERS * sizeof(unsigned long long)), "Couldn't allocate device memory");
             HIP_OK(hipMemsetAsync(I->d_counters, 0, CLW_NUM_COUNTERS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
@@ -485,18 +506,28 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         per_share = ((trows + 7) / 8) * tpr;
         grid = 8 * per_share;
         if (I->sched && !(I->variant & 4)) {
-            if (S.w != P.width || S.rows != P.rows || !S.cost) {
-                if (S.cost) (void)hipFree(S.cost);
-                if (S.order) (void)hipFree(S.order);
-                HIP_OK(hipMalloc((void**)&S.cost, (size_t)trows * tpr * 4), "Couldn't allocate device memory");
-                HIP_OK(hipMalloc((void**)&S.order, (size_t)grid * 4), "Couldn't allocate device memory");
-                S.w = P.width; S.rows = P.rows; S.valid = false;
+            if (S.w != P.width || S.rows != P.rows || !S.cost[0]) {
+                S.free_all();
+                for (int i = 0; i < 2; i++) {
+                    HIP_OK(hipMalloc((void**)&S.cost[i], (size_t)trows * tpr * 4), "Couldn't allocate device memory");
+                    HIP_OK(hipMalloc((void**)&S.order[i], (size_t)grid * 4), "Couldn't allocate device memory");
+                    HIP_OK(hipEventCreateWithFlags(&S.built[i], hipEventDisableTiming), "Couldn't create a timing event");
+                }
+                HIP_OK(hipEventCreateWithFlags(&S.traced, hipEventDisableTiming), "Couldn't create a timing event");
+                S.w = P.width; S.rows = P.rows; S.wr = 0;
             }
-            P.tile_cost = S.cost;
-            P.tile_order = S.valid ? S.order : nullptr;
+            const int wr = S.wr;
+            P.tile_cost = S.cost[wr];
+            /* the order built two frames ago is complete by now; the one built behind the previous frame may still be
+             * running (waiting for it costs that frame ~15 us, once) */
+            const int rd = S.have[wr] ? wr : (S.have[wr ^ 1] ? (wr ^ 1) : -1);
+            /* build(k-2) read cost[wr] and wrote order[wr]: it must have finished before this trace touches either */
+            if (S.have[wr]) HIP_OK(hipStreamWaitEvent(I->stream, S.built[wr], 0), "Couldn't run the kernel");
+            if (rd >= 0 && rd != wr) HIP_OK(hipStreamWaitEvent(I->stream, S.built[rd], 0), "Couldn't run the kernel");
+            P.tile_order = rd >= 0 ? S.order[rd] : nullptr;
             /* the costs can only change when the camera, the depth or the scene did */
-            sched_rebuild = !S.valid || !same_raygen(g, S.sig) || S.sig_depth != I->depth || S.sig_scene != I->scene_generation;
-            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; }
+            sched_rebuild = !S.sig_valid || !same_raygen(g, S.sig) || S.sig_depth != I->depth || S.sig_scene != I->scene_generation;
+            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; S.sig_valid = true; }
         }
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -507,10 +538,18 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
     if (e != hipSuccess) die("Couldn't run the kernel");
     t.done();
-    if (sched_rebuild) {
-        if (wt_fast_launch_sched(S.cost, S.order, tpr, trows, per_share, I->stream) != hipSuccess)
-            die("Couldn't run the kernel");
-        S.valid = true;
+    if (P.tile_cost) {
+        const int wr = S.wr;
+        if (sched_rebuild) {   /* sort this frame's costs behind it, on the side stream */
+            if (!I->sched_stream) HIP_OK(hipStreamCreateWithFlags(&I->sched_stream, hipStreamNonBlocking), "Couldn't create a command queue for the given device");
+            HIP_OK(hipEventRecord(S.traced, I->stream), "Couldn't run the kernel");
+            HIP_OK(hipStreamWaitEvent(I->sched_stream, S.traced, 0), "Couldn't run the kernel");
+            if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, I->sched_stream) != hipSuccess)
+                die("Couldn't run the kernel");
+            HIP_OK(hipEventRecord(S.built[wr], I->sched_stream), "Couldn't run the kernel");
+            S.have[wr] = true;
+        }
+        S.wr = wr ^ 1;
     }
 }
 
@@ -625,6 +664,7 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->timing_every = (uint32_t)env_int("CLWRAP_TIMING_EVERY", 1);
     if (I->timing_every == 0) I->timing_every = 1;
     I->pipeline = env_int("CLWRAP_PIPELINE", 1) ? 1 : 0;
+    I->stamps = env_int("CLWRAP_STAMPS", 0) ? 1 : 0;
     I->occ_tiles_per_depth = (unsigned)env_int("CLWRAP_OCC_TILES_PER_DEPTH", (int)OCC_TILES_PER_DEPTH);
 
     wrap->impl = I;
@@ -748,7 +788,9 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_counters) (void)hipFree(I->d_counters);
     for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
     if (I->d_grid_geom) (void)hipFree(I->d_grid_geom);
-    for (auto& sc : I->scheds) { if (sc.cost) (void)hipFree(sc.cost); if (sc.order) (void)hipFree(sc.order); }
+    if (I->sched_stream) (void)hipStreamSynchronize(I->sched_stream);
+    for (auto& sc : I->scheds) sc.free_all();
+    if (I->sched_stream) (void)hipStreamDestroy(I->sched_stream);
     if (I->copy_stream) (void)hipStreamDestroy(I->copy_stream);
     for (hipEvent_t e : I->chunk_done) if (e) (void)hipEventDestroy(e);
     for (auto& t : I->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -826,13 +868,13 @@ uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity
     use_device(I);
     finish(I);
     const Impl::Sched& S = I->scheds[0];
-    if (!S.cost) return 0;
+    if (!S.cost[0]) return 0;
     uint32_t n = ((S.rows + 7) / 8) * ((S.w + 7) / 8);
-    if (out && capacity >= n) HIP_OK(hipMemcpy(out, S.cost, (size_t)n * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    if (out && capacity >= n) HIP_OK(hipMemcpy(out, S.cost[S.wr ^ 1], (size_t)n * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
     return n;
 }
 void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 : 0; }
-void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; for (auto& sc : I->scheds) sc.valid = false; }
+void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; for (auto& sc : I->scheds) sc.reset(); }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
 

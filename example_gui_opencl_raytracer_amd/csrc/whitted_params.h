@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
-#define CLW_NUM_COUNTERS 12 /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex) */
+#define CLW_NUM_COUNTERS 32 /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex); 16.. = phase stamps of the diagnostic build */
 
 typedef struct {
     /* camera: the eight by-value raygen arguments (reference raygen.cl:5-8) */

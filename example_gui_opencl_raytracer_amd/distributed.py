@@ -2,10 +2,13 @@
 
 The reference is single-device (one platform, one device, one queue; reference
 src/opencl_wrap.c:26-34); pixels are independent work-items (raytracing.cl:23-37,194), so
-the path shards by contiguous row strips with no data-path collective.  The one exchange is
-a single gather of the finished strips to rank 0 -- RCCL over xGMI with backend "nccl",
-gloo on CPU for the tests.  Work-item ids stay GLOBAL (renderer.Renderer / clw_ext_set_id_offset)
-so the gathered image is bit-identical to a single-GPU render.
+the path shards by rows (contiguous strips, or interleaved 8-row bands for balance) with no data-path
+collective.  The one exchange is a single gather of the finished rows to rank 0 over xGMI: every rank
+stores its RGB888 share straight into rank 0's frame buffer (peer-mapped through a HIP IPC handle, one
+device-to-device copy per rank and frame) and a one-word all-reduce (RCCL, backend "nccl") tells rank 0
+the frame is complete; where peer mapping is not available the share travels by `torch.distributed.gather`
+(RCCL send/recv; gloo on CPU for the tests).  Work-item ids stay GLOBAL (renderer.Renderer /
+clw_ext_set_id_offset / clw_ext_set_row_bands) so the assembled image is bit-identical to a single-GPU render.
 """
 from __future__ import annotations
 
@@ -61,73 +64,157 @@ def gather_strips(strip: torch.Tensor, width: int, height: int, rank: int, world
     return full
 
 
-class BandGatherer:
-    """One gather per frame of every rank's interleaved 8-row bands to rank 0, with two frame slots so the
-    gather of frame k overlaps the trace of frame k+1.
+class FrameGatherer:
+    """One gather per frame of every rank's rows to rank 0, with two frame slots so the gather of frame k overlaps the
+    trace of frame k+1.
 
-    What travels is RGB888: the framebuffer word is 0x00RRGGBB, its top byte is always zero, so each share is
-    packed to 3 bytes per pixel first (a strided copy on a side stream) -- 25 % less on the xGMI links, which
-    are what bounds a gather into one GPU.  Rank r owns bands r, r+world, ... (renderer `bands=(world, rank)`),
-    so rank 0 receives `world` equal blocks and the full frame is their interleave (`assemble`)."""
+    layout "bands": rank r owns the 8-row bands r, r + world, ... (renderer `bands=(world, rank)`; equal shares);
+    layout "strips": rank r owns the contiguous rows `strip_rows(height, world, r)` (north_star's row strips).
 
-    def __init__(self, width: int, height: int, rank: int, world: int, device, staged_on_cpu=False):
-        assert height % (8 * world) == 0, "interleaved bands need height % (8 * world) == 0"
-        self.width, self.height, self.rank, self.world = width, height, rank, world
-        self.px_rank = width * height // world
+    What travels is RGB888: the framebuffer word is 0x00RRGGBB, its top byte is always zero, so each share is packed
+    to 3 bytes per pixel first (a strided copy on a side stream) -- 25 % less on the xGMI links, which are what
+    bounds a gather into one GPU.  Rank 0 keeps, per slot, one row of `px_max * 3` bytes per rank (`parts`);
+    `assemble` turns that into the 0x00RRGGBB frame.
+
+    transport "peer": rank 0's `parts` are mapped into every rank through a HIP IPC handle and each rank writes its
+    row with ONE device-to-device copy over its own xGMI link -- no send/recv kernels, no staging; a one-word
+    all-reduce behind the copies is the completion signal.  transport "gather": `torch.distributed.gather`.
+    "auto" tries "peer" on GPUs and falls back to "gather" when the mapping cannot be set up."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, layout: str = "bands",
+                 transport: str = "auto", staged_on_cpu: bool = False):
+        assert layout in ("bands", "strips")
+        if layout == "bands":
+            assert height % (8 * world) == 0, "interleaved bands need height % (8 * world) == 0"
+        self.width, self.height, self.rank, self.world, self.layout = width, height, rank, world, layout
+        self.rows = [height // world] * world if layout == "bands" else [strip_rows(height, world, r)[1] for r in range(world)]
+        self.px = [r * width for r in self.rows]
+        self.px_rank, self.px_max = self.px[rank], max(self.px)
         self.staged = staged_on_cpu           # rehearsal with gloo: collectives on CPU copies
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda" and not staged_on_cpu
         cdev = self.device if self.on_gpu else torch.device("cpu")
-        self.packed = [torch.empty(self.px_rank * 3, dtype=torch.uint8, device=cdev) for _ in range(2)]
-        self.parts = [[torch.empty(self.px_rank * 3, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
-                      for _ in range(2)]
+        self.packed = [torch.zeros(self.px_max * 3, dtype=torch.uint8, device=cdev) for _ in range(2)]
         self.pending = [None, None]
         self.comm = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.ev_packed = [torch.cuda.Event() if self.on_gpu else None for _ in range(2)]
         self.used = [False, False]
+        self.flag = torch.zeros(1, dtype=torch.int32, device=cdev)
+        self.parts = [None, None]             # rank 0: uint8 [world, px_max * 3] per slot
+        self.peer = [None, None]              # every rank (peer transport): rank 0's `parts`, mapped here
+        self.transport = "gather"
+        if world > 1:
+            if transport in ("auto", "peer") and self.device.type == "cuda":
+                self.transport = "peer" if self._map_peer_buffers() else "gather"
+                if transport == "peer" and self.transport != "peer":
+                    raise RuntimeError("peer-mapped gather buffers could not be set up")
+            if self.transport == "gather" and rank == 0:
+                self.parts = [torch.zeros(world, self.px_max * 3, dtype=torch.uint8, device=cdev) for _ in range(2)]
+
+    # ---- peer transport: rank 0 allocates, everybody maps -----------------------------------------------------
+    def _map_peer_buffers(self) -> bool:
+        """Rank 0 shares its two `parts` buffers through HIP IPC handles (what torch.multiprocessing uses for CUDA
+        tensors); all ranks agree on success through an all-reduce, so either everybody uses the mapping or nobody."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        ok, handles = 1, [None, None]
+        try:
+            if self.rank == 0:
+                self.parts = [torch.zeros(self.world, self.px_max * 3, dtype=torch.uint8, device=self.device) for _ in range(2)]
+                handles = [reduce_tensor(t) for t in self.parts]
+        except Exception:
+            ok = 0
+        box = [handles]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            if self.rank == 0:
+                self.peer = list(self.parts)
+            elif box[0][0] is not None:
+                self.peer = [fn(*args) for (fn, args) in box[0]]
+                self.peer[0][self.rank, :1].copy_(self.packed[0][:1])        # touch it: enables peer access now, not in the timed loop
+                torch.cuda.synchronize(self.device)
+            else:
+                ok = 0
+        except Exception:
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != 1:
+            self.peer = [None, None]
+            if self.rank == 0:
+                self.parts = [None, None]
+            return False
+        return True
 
     def before_render(self, slot: int) -> None:
         """Call before tracing into the slot's framebuffer again: its previous contents must have been packed."""
         if self.on_gpu and self.used[slot]:
             torch.cuda.current_stream(self.device).wait_event(self.ev_packed[slot])
 
+    def _wait(self, slot: int) -> None:
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+
     def submit(self, slot: int, share: torch.Tensor) -> None:
         """share: int32 [px_rank] framebuffer of this rank (0x00RRGGBB), just rendered on the current stream."""
         if self.world == 1:
             return
+        n3 = self.px_rank * 3
         bgr = share.view(torch.uint8).view(-1, 4)[:, :3]         # little-endian: B, G, R, 0
         if self.on_gpu:
             rendered = torch.cuda.Event()
             rendered.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(rendered)
-                if self.pending[slot] is not None:
-                    self.pending[slot].wait()                     # the gather that still reads packed[slot]
-                self.packed[slot].view(-1, 3).copy_(bgr)
+                self._wait(slot)                                  # the transfer that still reads packed[slot]
+                self.packed[slot][:n3].view(-1, 3).copy_(bgr)
                 self.ev_packed[slot].record(self.comm)
-                self.pending[slot] = dist.gather(self.packed[slot], gather_list=self.parts[slot], dst=0, async_op=True)
+                if self.transport == "peer":
+                    self.peer[slot][self.rank, :n3].copy_(self.packed[slot][:n3], non_blocking=True)   # one copy over this rank's link
+                    self.pending[slot] = dist.all_reduce(self.flag, async_op=True)                     # "frame complete" for rank 0
+                else:
+                    self.pending[slot] = dist.gather(self.packed[slot], gather_list=list(self.parts[slot]) if self.rank == 0 else None,
+                                                     dst=0, async_op=True)
             self.used[slot] = True
         else:
-            if self.pending[slot] is not None:
-                self.pending[slot].wait()
-            self.packed[slot].view(-1, 3).copy_(bgr.cpu() if share.is_cuda else bgr)
-            self.pending[slot] = dist.gather(self.packed[slot], gather_list=self.parts[slot], dst=0, async_op=True)
+            self._wait(slot)
+            self.packed[slot][:n3].view(-1, 3).copy_(bgr.cpu() if share.is_cuda else bgr)
+            if self.transport == "peer":                          # rehearsal on one GPU: the mapping is real, the signal is gloo's
+                self.peer[slot][self.rank, :n3].copy_(self.packed[slot][:n3].to(self.device))
+                torch.cuda.synchronize(self.device)
+                self.pending[slot] = dist.all_reduce(self.flag, async_op=True)
+            else:
+                self.pending[slot] = dist.gather(self.packed[slot], gather_list=list(self.parts[slot]) if self.rank == 0 else None,
+                                                 dst=0, async_op=True)
 
     def drain(self) -> None:
         for slot in (0, 1):
             if self.pending[slot] is not None:
                 if self.on_gpu:
                     with torch.cuda.stream(self.comm):
-                        self.pending[slot].wait()
+                        self._wait(slot)
                 else:
-                    self.pending[slot].wait()
-                self.pending[slot] = None
+                    self._wait(slot)
         if self.on_gpu:
             self.comm.synchronize()
 
+    def assemble_rgb(self, slot: int) -> torch.Tensor:
+        """Rank 0: the last frame gathered into `slot` as uint8 [height * width, 3] in B, G, R byte order."""
+        assert self.rank == 0
+        parts = self.parts[slot]
+        if self.layout == "bands":
+            nb = self.height // (8 * self.world)                  # bands per rank
+            return torch.stack([parts[r].view(nb, 8 * self.width * 3) for r in range(self.world)], 1).reshape(-1, 3)
+        return torch.cat([parts[r][: self.px[r] * 3] for r in range(self.world)]).view(-1, 3)
+
     def assemble(self, slot: int) -> torch.Tensor:
         """Rank 0: the full frame as int32 [height * width] (0x00RRGGBB) of the last frame gathered into `slot`."""
-        assert self.rank == 0
-        nb = self.height // (8 * self.world)                      # bands per rank
-        rgb = torch.stack([p.view(nb, 8 * self.width * 3) for p in self.parts[slot]], 1).reshape(-1, 3).to(torch.int32)
+        rgb = self.assemble_rgb(slot).to(torch.int32)
         return (rgb[:, 2] << 16) | (rgb[:, 1] << 8) | rgb[:, 0]
+
+
+class BandGatherer(FrameGatherer):
+    """FrameGatherer with interleaved 8-row bands (bench.py's weak-scaling mode)."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, staged_on_cpu=False, transport="auto"):
+        super().__init__(width, height, rank, world, device, layout="bands", transport=transport, staged_on_cpu=staged_on_cpu)

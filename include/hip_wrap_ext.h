@@ -109,7 +109,8 @@ void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
 /* The same with the later words: out[8] = shadow rays really TRACED.  out[1] counts every shadow ray the reference
  * would cast; those of a surface whose specular and diffuse coefficients are both zero (glass)
  * contribute exactly +0, so the kernel draws their random numbers but does not trace them -- out[8] leaves them
- * out.  n <= 12 words are returned (the rest reads 0), and the device block is cleared. */
+ * out.  n <= 32 words are returned (the rest reads 0), and the device block is cleared.  Words 16.. are
+ * only written by the diagnostic stamp build of the kernel (tools/stamp_phases.py). */
 void clw_ext_read_counters_ex(cl_wrap* wrap, uint64_t* out, uint32_t n);
 
 /* Uniform grid over the spheres (default on; built for scenes with more than 256 spheres): rays test only the

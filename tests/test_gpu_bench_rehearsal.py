@@ -1,6 +1,8 @@
-"""bench.py's N > 1 path on the ONE-GPU box: two ranks share cuda:0 and gather through gloo (RCCL needs distinct
-GPUs), everything else -- interleaved bands with global ids, the side-stream RGB888 packing, the double-buffered
-gather, the assembly on rank 0 -- is the code the 8-GPU run uses.  The assembled frame must equal a single-GPU render."""
+"""bench.py's N > 1 paths on the ONE-GPU box: two ranks share cuda:0 and talk through gloo (RCCL needs distinct GPUs);
+everything else -- global ids, interleaved bands / row strips, the side-stream RGB888 packing, the double-buffered
+transfer into rank 0's frame buffer (peer-mapped through a HIP IPC handle, or torch.distributed.gather), the assembly
+on rank 0 and, for config C5, the single PNG -- is the code the 8-GPU run uses.  The assembled frame must equal a
+single-GPU render."""
 import json
 import os
 import socket
@@ -21,23 +23,57 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("device_tensors", [False, True])
-def test_two_rank_bench_assembles_the_single_gpu_frame(demo_scene, tex, tmp_path, device_tensors):
-    import torch  # noqa: F401
-    from example_gui_opencl_raytracer_amd import api, textures
-    from example_gui_opencl_raytracer_amd.renderer import Renderer
-    png = str(tmp_path / "bands.png")
+def _run_bench(extra, png):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--rehearse", "--dump-png", png] + (["--rehearse-device-tensors"] if device_tensors else [])
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--dump-png", png] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frame"] == "1920x2160" and line["value"] > 0
-    img = api.read_png(png)
-    got = (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
-    r = Renderer(demo_scene, tex, textures.skybox_cross(4096), 1920, 2160, depth=4)
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _single_gpu_frame(demo_scene, tex, w, h):
+    import torch  # noqa: F401
+    from example_gui_opencl_raytracer_amd import textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    r = Renderer(demo_scene, tex, textures.skybox_cross(4096), w, h, depth=4)
     r.look(**CAM)
     want = r.render()
     r.release()
+    return want
+
+
+def _png_frame(path):
+    from example_gui_opencl_raytracer_amd import api
+    img = api.read_png(path)
+    return (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
+
+
+@pytest.mark.parametrize("extra", [["--transport", "gather"], ["--transport", "gather", "--rehearse-device-tensors"],
+                                   ["--transport", "peer"], ["--transport", "peer", "--rehearse-device-tensors"]],
+                         ids=["gather-staged", "gather-device", "peer-staged", "peer-device"])
+def test_two_rank_weak_scaling_assembles_the_single_gpu_frame(demo_scene, tex, tmp_path, extra):
+    png = str(tmp_path / "bands.png")
+    line = _run_bench(["--steps", "6", "--warmup", "2"] + extra, png)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frame"] == "1920x2160" and line["value"] > 0
+    assert extra[1] in line["config"]["sharding"] and line["value_per_gpu"] == pytest.approx(line["value"] / 2, rel=1e-3)
+    assert np.array_equal(_png_frame(png), _single_gpu_frame(demo_scene, tex, 1920, 2160))
+
+
+def test_two_rank_strong_scaling_splits_the_fixed_frame(demo_scene, tex, tmp_path):
+    """north_star's split: the FIXED 1920x1080 frame in contiguous row strips (536 + 544 rows here)."""
+    png = str(tmp_path / "strips.png")
+    line = _run_bench(["--steps", "6", "--warmup", "2", "--scaling", "strong", "--transport", "peer"], png)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["frame"] == "1920x1080"
+    assert 13.8 < line["config"]["rays_per_pixel"] < 13.95
+    assert np.array_equal(_png_frame(png), _single_gpu_frame(demo_scene, tex, 1920, 1080))
+
+
+def test_two_rank_c5_writes_the_single_png(demo_scene, tex, tmp_path):
+    """BASELINE config 5 with two strips: 8192x8192, depth 4, the single PNG written by rank 0."""
+    png = str(tmp_path / "c5.png")
+    line = _run_bench(["--steps", "2", "--warmup", "1", "--config", "c5"], png)
+    assert line["scaling"] == "strong" and line["config"]["frame"] == "8192x8192" and line["png"]["write_s"] > 0
+    assert line["png"]["bytes"] == os.path.getsize(png)
+    got = _png_frame(png)
+    want = _single_gpu_frame(demo_scene, tex, 8192, 8192)
     assert np.array_equal(got, want)

@@ -1,16 +1,19 @@
 """GPU parity tests: the HIP path, called through the C-ABI (cl_wrap_*), against the oracle.
 
 Bars (written here as the tolerances):
-  strict build  (no contraction, IEEE divide/sqrt)   >= 99.9 % of pixels bit-exact, ray counts equal
+  strict build  (no contraction, IEEE divide/sqrt)   EVERY pixel bit-exact (np.array_equal), ray counts equal
   fast build    (explicit FMAs, native rcp/sqrt, ...)  >= 99.8 % bit-exact, >= 99.9 % within 1 LSB per channel on
                                                      render.map frames (99.9 / 99.95 % at the full C2 size; looser on
-                                                     the chaotic glass-field scene), float radiance within 1e-4 on >= 99.5 %
+                                                     the chaotic glass-field scene); every pixel that differs by more
+                                                     than 1 LSB lies on the frame's discontinuity mask
+                                                     (tests/golden/masks.npz) and the float radiance of EVERY pixel off
+                                                     the mask is within 1e-4 (north_star's tolerance)
   integer / index work (raygen records are fp but must be bit-exact; ids, packing) bit-exact.
 """
 import numpy as np
 import pytest
 
-from conftest import CAM, channel_diff
+from conftest import CAM, channel_diff, frame_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +33,12 @@ def gpu_frame(R, sc, tex, sky, w, h, depth, strict, cam=CAM, rgb=False, **kw):
     return out
 
 
+def check_exact(got, want, what=""):
+    """The strict build's bar: every pixel equal."""
+    bad = int((got != want).sum())
+    assert got.shape == want.shape and bad == 0, f"{what}: {bad} of {got.size} pixels differ from the oracle"
+
+
 def check(got, want, exact_min, le1_min=None):
     d = channel_diff(got, want)
     exact, le1 = (d == 0).mean(), (d <= 1).mean()
@@ -40,16 +49,53 @@ def check(got, want, exact_min, le1_min=None):
 
 
 # ------------------------------------------------------------ golden frames (reference kernels' own output)
-@pytest.mark.parametrize("w,h,depth", [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)])
+GOLDEN_FRAMES = [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4), (640, 480, 1)]   # (640, 480, 1) = BASELINE config C1
+
+
+@pytest.mark.parametrize("w,h,depth", GOLDEN_FRAMES)
 def test_strict_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w, h, depth):
     got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=True)
-    check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.999)
+    check_exact(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], f"strict {w}x{h} d{depth}")
 
 
-@pytest.mark.parametrize("w,h,depth", [(160, 120, 1), (160, 120, 4), (160, 120, 15), (320, 240, 4)])
+@pytest.mark.parametrize("w,h,depth", GOLDEN_FRAMES)
 def test_fast_matches_golden_frames(R, demo_scene, tex, sky, golden_frames, w, h, depth):
     got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=False)
     check(got, golden_frames[f"render_map_{w}x{h}_d{depth}"], 0.998, 0.999)
+
+
+MASK_REPORT = {}
+
+
+@pytest.mark.parametrize("w,h,depth", GOLDEN_FRAMES + [(1280, 720, 4)])
+def test_fast_outliers_lie_on_the_discontinuity_mask(R, oracle, demo_scene, tex, sky, golden_frames, golden_masks, w, h, depth):
+    """SURVEY.md 8(c) bar (2)+(3) for the BENCHMARKED build.  The mask of a frame (oracle/gen_golden.py) marks the pixels
+    where the reference's own output is discontinuous or decided within rounding error: two legal builds of the
+    reference kernels (contraction off / on) disagree there (dilated 1 px), or the oracle's radiance is not locally
+    linear under camera shifts of 1/64 .. 1/1024 pixel, or a sphere discriminant / texel-index truncation has a
+    relative margin below 1e-5 / 2e-6.  Claim: every fast-build pixel more than 1 LSB away from the reference frame lies
+    on the mask, and OFF the mask the float radiance of every pixel is within 1e-4 of the oracle's."""
+    import zlib
+    key = f"render_map_{w}x{h}_d{depth}"
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    want, want_rgb, _ = oracle.render(cam, demo_scene, tex, sky, depth, want_rgb=True)
+    assert zlib.crc32(want.tobytes()) == int(golden_masks[key + "_crc32"][0])     # = the reference kernels' frame
+    got, rgb = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=False, rgb=True)
+    mask = frame_mask(golden_masks, key, w * h)
+    d = channel_diff(got, want)
+    outl = d > 1
+    with np.errstate(invalid="ignore"):
+        err = np.abs(rgb - want_rgb).max(1)
+    err = np.where(np.isnan(rgb).any(1) & np.isnan(want_rgb).any(1), 0.0, np.nan_to_num(err, nan=np.inf))
+    far = err > 1e-4
+    parts = {n: frame_mask(golden_masks, key, w * h, (n,)) for n in ("fma", "jitter", "margin")}
+    MASK_REPORT[key] = dict(mask=float(mask.mean()), differing=int((d > 0).sum()), outliers=int(outl.sum()),
+                            outliers_off_mask=int((outl & ~mask).sum()), rgb_far=int(far.sum()), rgb_far_off_mask=int((far & ~mask).sum()),
+                            outliers_on={n: int((outl & m).sum()) for n, m in parts.items()}, max_err_off_mask=float(err[~mask].max()))
+    print("mask report", key, MASK_REPORT[key])
+    assert mask.mean() < (0.10 if w >= 640 else 0.20)
+    assert (outl & ~mask).sum() == 0, f"{key}: {(outl & ~mask).sum()} outliers (> 1 LSB) off the mask: {MASK_REPORT[key]}"
+    assert (far & ~mask).sum() == 0, f"{key}: {(far & ~mask).sum()} pixels off the mask differ by more than 1e-4: {MASK_REPORT[key]}"
 
 
 def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
@@ -61,7 +107,7 @@ def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
     err = np.abs(rgb - want).max(1)
     assert (err <= 1e-4).mean() >= 0.995
     _, rgb_s = gpu_frame(R, demo_scene, tex, sky, w, h, depth, strict=True, rgb=True)
-    assert (np.abs(rgb_s - want).max(1) <= 1e-4).mean() >= 0.999
+    assert np.array_equal(rgb_s.view(np.uint32), want.view(np.uint32)), "strict float radiance differs from the oracle's"
 
 
 # ------------------------------------------------------------ other scenes / cameras vs the oracle
@@ -76,7 +122,7 @@ def test_cameras(R, oracle, demo_scene, tex, sky, origin, look, fov):
     w, h, depth = 128, 96, 15
     cam = dict(origin=origin, look=look, fov=fov, focal=1.0)
     want, _, _ = oracle.render(oracle.camera(origin, look, fov, 1.0, w, h), demo_scene, tex, sky, depth)
-    check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check_exact(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=cam), want, f"camera {origin}")
     check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
 
 
@@ -90,7 +136,7 @@ def test_degenerate_camera_nan_propagation(R, oracle, demo_scene, tex, sky):
     want, rgb, _ = oracle.render(oracle.camera(origin, look, fov, 1.0, w, h), demo_scene, tex, sky, depth, want_rgb=True)
     assert np.isnan(rgb).any()
     got = gpu_frame(R, demo_scene, tex, sky, w, h, depth, True, cam=dict(origin=origin, look=look, fov=fov, focal=1.0))
-    check(got, want, 0.999)
+    check_exact(got, want, "NaN propagation")
 
 
 @pytest.mark.parametrize("depth", [1, 2, 4, 5, 8, 15, 32])
@@ -98,7 +144,7 @@ def test_depths_including_the_scratch_stack(R, oracle, demo_scene, tex, sky, dep
     """depth <= 4 keeps the DFS stack in LDS; deeper levels spill to scratch (other kernel build)."""
     w, h = 160, 120
     want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, depth)
-    check(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True), want, 0.999)
+    check_exact(gpu_frame(R, demo_scene, tex, sky, w, h, depth, True), want, f"depth {depth}")
     if depth >= 8:
         assert cnt.max_stack > 4          # the deep levels really are exercised
 
@@ -111,7 +157,7 @@ def test_glass_field_divergence_scene(R, oracle, tex, sky):
     w, h, depth = 256, 256, 8
     want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
     assert cnt.pushes > 10000 and cnt.max_stack >= 4
-    check(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check_exact(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, "glass field")
     check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.98, 0.99)
 
 
@@ -123,7 +169,7 @@ def test_many_spheres_wide_counts_and_global_geometry_path(R, oracle, tex, sky):
     cam = dict(origin=(0.0, 6.0, -6.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
     w, h, depth = 96, 54, 2
     want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
-    check(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, 0.999)
+    check_exact(gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam), want, "1600 spheres")
     check(gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam), want, 0.99, 0.995)
 
 
@@ -159,7 +205,36 @@ def test_uniform_grid_equals_linear_scan(R, oracle, tex, sky, cam, kind):
             r.release()
         assert np.array_equal(outs[(strict, 1)], outs[(strict, 0)])
     want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth)
-    check(outs[(True, 1)], want, 0.999)
+    check_exact(outs[(True, 1)], want, f"grid {kind}")
+
+
+def test_nan_rays_on_the_grid_path_end_like_the_linear_scan(R, oracle, tex, sky):
+    """A scene of more than 256 spheres (uniform-grid build) whose rays go NaN: the camera sits at the exact centre
+    of a glass sphere, so view and light directions cancel, normalize(0) = NaN poisons radiance and directions, and
+    the next segments are traced with NaN rays.  The grid walk must end (it has no cells to walk for such a ray and
+    takes the reference's in-order scan instead) and give the same pixels as the linear-scan build and the oracle."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sc = scene.sphere_grid_scene(24, 24)
+    g = scene.glass()
+    for name in ("ambient", "diffuse", "specular", "shininess", "transperent", "dielectric", "n", "reflectivity"):
+        sc.spheres["material"][name][:] = g[name]
+    sc.spheres["radius"][:] = 0.55
+    sc = scene.Scene(sc.spheres, sc.planes, sc.lights)
+    c = sc.spheres["origin"][300]
+    cam = dict(origin=(float(c[0]), float(c[1]), float(c[2])), look=(0.3, -0.2, 1.0), fov=100.0, focal=1.0)
+    w, h, depth = 96, 64, 6
+    want, rgb, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth, want_rgb=True)
+    assert np.isnan(rgb).any()
+    outs = {}
+    for grid in (1, 0):
+        r = Renderer(sc, tex, sky, w, h, depth=depth, strict=True)
+        r.w.set_grid(grid)
+        r.look(**cam)
+        outs[grid] = r.render()
+        r.release()
+    assert np.array_equal(outs[1], outs[0])
+    check_exact(outs[1], want, "NaN rays on the grid path")
 
 
 def test_lds_and_global_geometry_paths_agree_exactly(R, demo_scene, tex, sky):
@@ -201,8 +276,7 @@ def test_cost_sorted_dispatch_is_pure_scheduling(R, demo_scene, tex, sky):
 def test_ragged_sizes(R, oracle, demo_scene, tex, sky, w, h):
     want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky, 4)
     got = gpu_frame(R, demo_scene, tex, sky, w, h, 4, True)
-    assert got.shape == want.shape
-    check(got, want, 0.995 if w * h > 1000 else 0.95)
+    check_exact(got, want, f"ragged {w}x{h}")
 
 
 def test_empty_primitive_lists(R, oracle, demo_scene, tex, sky):
@@ -218,7 +292,7 @@ def test_empty_primitive_lists(R, oracle, demo_scene, tex, sky):
     for name, sc in cases.items():
         want, _, _ = oracle.render(cam, sc, tex, sky, 4)
         got = gpu_frame(R, sc, tex, sky, w, h, 4, True)
-        assert (channel_diff(got, want) == 0).mean() >= 0.999, name
+        check_exact(got, want, name)
 
 
 @pytest.mark.parametrize("nl", [1, 2, 4, 7])
@@ -236,8 +310,8 @@ def test_light_counts_around_the_chunk_size(R, oracle, demo_scene, tex, sky, nl)
     w, h = 128, 96
     want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 6)
     assert cnt.shadow_rays == 2 * nl * cnt.shaded_hits
-    check(gpu_frame(R, sc, tex, sky, w, h, 6, True), want, 0.999)       # depth 6: deep build, sparse-tail loop too
-    check(gpu_frame(R, sc, tex, sky, w, h, 4, True), oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 4)[0], 0.999)
+    check_exact(gpu_frame(R, sc, tex, sky, w, h, 6, True), want, f"{nl} lights d6")       # depth 6: deep build, sparse-tail loop too
+    check_exact(gpu_frame(R, sc, tex, sky, w, h, 4, True), oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), sc, tex, sky, 4)[0], f"{nl} lights d4")
 
 
 def test_maximum_one_byte_counts(R, oracle, tex, sky):
@@ -263,7 +337,7 @@ def test_maximum_one_byte_counts(R, oracle, tex, sky):
     w, h = 48, 32
     want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, 2)
     assert cnt.shadow_rays == 510 * cnt.shaded_hits
-    check(gpu_frame(R, sc, tex, sky, w, h, 2, True, cam=cam, wide_counts=False), want, 0.995)
+    check_exact(gpu_frame(R, sc, tex, sky, w, h, 2, True, cam=cam, wide_counts=False), want, "255 spheres / 255 lights")
 
 
 def test_odd_image_sizes(R, oracle, demo_scene):
@@ -284,7 +358,7 @@ def test_odd_image_sizes(R, oracle, demo_scene):
     assert cnt.texel_fetches > 0 and cnt.sky_fetches > 0
     got = gpu_frame(R, sc, tex, sky, w, h, 4, True)
     if cnt.oob_reads == 0 and cnt.int_cast_oor == 0:
-        check(got, want, 0.999)
+        check_exact(got, want, "odd image sizes")
     else:                                                       # undefined reads in the reference: both sides clamp to the edge
         check(got, want, 0.995)
 
@@ -312,17 +386,22 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
     w, h, depth = 1920, 1080, 4
     want, _, cnt = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h), demo_scene, tex, sky4k, depth)
     assert 13.8 < cnt.rays / (w * h) < 13.95                      # 13.88 rays/px
-    for strict, bar in ((True, 0.9995), (False, 0.999)):
+    for strict in (True, False):
         r = Renderer(demo_scene, tex, sky4k, w, h, depth=depth, strict=strict)
         r.look(**CAM)
         got = r.render()
-        check(got, want, bar, None if strict else 0.9995)
+        if strict:
+            check_exact(got, want, "C2 strict")
+        else:
+            check(got, want, 0.999, 0.9995)
         r.w.enable_counters(1)
         r.render(readback=False)
         c = r.w.read_counters()
         r.release()
         rays = c["segments"] + c["shadow_rays"]
         assert abs(rays - cnt.rays) <= (0 if strict else 2e-4 * cnt.rays)
+        # shadow rays really traced: the ones of zero-coefficient (glass) surfaces are drawn from the RNG but elided
+        assert 0.5 * c["shadow_rays"] < c["shadow_rays_traced"] <= c["shadow_rays"]
         if strict:
             assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"]) == \
                    (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches)
@@ -363,9 +442,10 @@ def test_full_size_c3_glass_field_against_the_oracle(R, oracle, tex):
     assert 29.0 < cnt.rays / (w * h) < 30.0
     r = Renderer(sc, tex, sky4k, w, h, depth=8, strict=True)
     r.look(**cam)
-    check(r.render(), want, 0.9995)
+    check_exact(r.render(), want, "C3 strict")
     r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.release()
     assert c["segments"] + c["shadow_rays"] == cnt.rays
+    assert c["shadow_rays_traced"] < 0.5 * c["shadow_rays"]       # a field of glass: most counted shadow rays are elided
     r = Renderer(sc, tex, sky4k, w, h, depth=8, strict=False)
     r.look(**cam)
     check(r.render(), want, 0.99, 0.995)
@@ -384,9 +464,14 @@ def test_full_size_c4_ten_thousand_spheres_against_the_oracle(R, oracle, tex):
     want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky4k, 4)
     r = Renderer(sc, tex, sky4k, w, h, depth=4, strict=True)
     r.look(**cam)
-    check(r.render(), want, 0.9995)
+    check_exact(r.render(), want, "C4 strict")
     r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.release()
     assert c["segments"] + c["shadow_rays"] == cnt.rays
+    assert c["shadow_rays_traced"] == c["shadow_rays"]            # opaque plastic everywhere: nothing is elided
+    r = Renderer(sc, tex, sky4k, w, h, depth=4, strict=False)      # the benchmarked build at the full size
+    r.look(**cam)
+    check(r.render(), want, 0.998, 0.999)
+    r.release()
 
 
 def test_full_size_c5_strips_equal_the_single_gpu_frame(R, oracle, demo_scene, tex):
@@ -412,7 +497,7 @@ def test_full_size_c5_strips_equal_the_single_gpu_frame(R, oracle, demo_scene, t
         assert zlib.crc32(got.tobytes()) == zlib.crc32(want[r0 * w:(r0 + rows) * w].tobytes())
         if rank in (3, 5):
             ref, _, _ = oracle.render(cam, demo_scene, tex, sky4k, 4, id_begin=r0 * w, id_end=(r0 + 64) * w)
-            check(got[:64 * w], ref, 0.9995)
+            check_exact(got[:64 * w], ref, f"C5 strip {rank}")
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -425,8 +510,7 @@ def test_random_scenes_against_the_oracle(R, oracle, tex, sky, seed):
     if cnt.int_cast_oor or cnt.oob_reads:
         pytest.skip("scene hits an undefined float->int conversion / image read in the reference")
     got = gpu_frame(R, sc, tex, sky, w, h, depth, True, cam=cam)
-    d = channel_diff(got, want)
-    assert (d == 0).mean() >= 0.995, f"seed {seed}: strict build {(d == 0).mean():.4f} exact"
+    check_exact(got, want, f"fuzz seed {seed}")
     fast = gpu_frame(R, sc, tex, sky, w, h, depth, False, cam=cam)
     df = channel_diff(fast, want)
     assert (df <= 1).mean() >= 0.97, f"seed {seed}: fast build {(df <= 1).mean():.4f} within 1 LSB"

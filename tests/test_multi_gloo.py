@@ -98,3 +98,41 @@ def test_interleaved_bands_gather_to_the_single_rank_frame(oracle, demo_scene, t
     cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
     want, _, _ = oracle.render(cam, demo_scene, tex, sky, DEPTH)
     assert np.array_equal(got, want)
+
+
+def _strip_gatherer_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from example_gui_opencl_raytracer_amd import distributed as D, scene, textures
+    from example_gui_opencl_raytracer_amd.renderer import strip_rows
+    from oracle.oracle_py import Oracle
+    D.init_process_group("gloo")
+    o = Oracle()
+    sc, tex, sky = scene.render_map_scene(), textures.texture_layers(), textures.skybox_cross(512)
+    cam = o.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H)
+    r0, rows = strip_rows(H, world, rank)
+    strip, _, _ = o.render(cam, sc, tex, sky, DEPTH, id_begin=r0 * W, id_end=(r0 + rows) * W, threads=1)
+    gat = D.FrameGatherer(W, H, rank, world, torch.device("cpu"), layout="strips")
+    assert gat.transport == "gather" and gat.rows == [strip_rows(H, world, r)[1] for r in range(world)]
+    for frame in range(3):                          # both slots, and reuse of slot 0
+        gat.before_render(frame & 1)
+        gat.submit(frame & 1, torch.from_numpy(strip.view(np.int32)))
+    gat.drain()
+    dist.barrier()
+    if rank == 0:
+        assert torch.equal(gat.assemble(0), gat.assemble(1))
+        np.save(out_path, gat.assemble(0).numpy().view(np.uint32))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_unequal_row_strips_through_the_frame_gatherer(oracle, demo_scene, tex, sky, tmp_path, world):
+    """bench.py --scaling strong / --config c5: contiguous strips of unequal height (60 rows: 32/28 and 24/24/12),
+    padded to the tallest for the transfer, assembled on rank 0."""
+    out = str(tmp_path / f"strips_{world}.npy")
+    mp.spawn(_strip_gatherer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H)
+    want, _, _ = oracle.render(cam, demo_scene, tex, sky, DEPTH)
+    assert np.array_equal(np.load(out), want)

@@ -1,5 +1,5 @@
 """Condense a tools/profile_round.sh output directory into small text files for profiles/."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, os, re, sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 out = []
@@ -11,7 +11,8 @@ info = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "wt_trace" not in k or "<5>" in k or "<7>" in k:     # skip the one-off counting build
+        m = re.search(r"wt_trace<(\d+)>", k)
+        if not m or int(m.group(1)) & 1:                       # skip the one-off counting build (flag bit 0)
             continue
         pm.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
         info[k] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
