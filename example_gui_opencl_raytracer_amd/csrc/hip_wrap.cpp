@@ -43,9 +43,11 @@ enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC =
  * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
 constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
+constexpr size_t COUNTER_WORDS = CLW_NUM_COUNTERS + 16 * (size_t)CLW_STAMP_SHARDS;
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
+constexpr size_t MAT_LDS_MAX_F4 = 128;   /* <= 2 KiB: geometry + materials + texture rows all in LDS */
 constexpr int SHALLOW_LEVELS = 3;   /* DFS levels the shallow builds provide (LDS + scratch): depth <= SHALLOW_LEVELS + 1 */
 constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes beyond the reference's one-byte counts get the uniform grid (at 64 spheres it only
                                                 wins when the cells happen to align with the spheres: 9.2-15 ms vs 10.9 ms linear) */
@@ -135,6 +137,7 @@ struct Impl {
     uint32_t prep_ns = 0, prep_np = 0, prep_nl = 0;
     float* d_geom = nullptr; size_t geom_f4 = 0;
     float* d_ptex = nullptr;
+    bool have_lpt = false;    /* the light / plane side table follows the lights in d_geom */
     uint64_t scene_generation = 0;   /* bumped every time the prepared scene is rebuilt (device pointers can be reused) */
     uint32_t *d_grid_start = nullptr, *d_grid_items = nullptr, *d_grid_box = nullptr;
     float* d_grid_geom = nullptr;
@@ -351,9 +354,12 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     const uint8_t* hs = host_view(I, s, 96 * (size_t)ns, ts);
     const uint8_t* hp = host_view(I, p, 96 * (size_t)np, tp);
     const uint8_t* hl = host_view(I, l, 48 * (size_t)nl, tl);
-    size_t f4 = wprep_geom_f4(ns, np, nl);
+    const size_t base_f4 = wprep_geom_f4(ns, np, nl), lpt_f4 = wprep_lpt_f4(np, nl);
+    size_t f4 = base_f4 + lpt_f4;
     std::vector<float> geom(4 * (f4 ? f4 : 1)), ptex(8 * (size_t)(np ? np : 1));
     wprep_build(hs, ns, hp, np, hl, nl, geom.data(), ptex.data());
+    wprep_build_lpt(hp, np, hl, nl, geom.data() + 4 * base_f4);
+    I->have_lpt = lpt_f4 != 0;
     if (I->d_geom) { (void)hipFree(I->d_geom); I->d_geom = nullptr; }
     if (I->d_ptex) { (void)hipFree(I->d_ptex); I->d_ptex = nullptr; }
     HIP_OK(hipMalloc((void**)&I->d_geom, geom.size() * 4), "Couldn't allocate device memory");
@@ -409,6 +415,7 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
     prepare_scene(I, bs, ns, bp, np, bl, nl);
     ensure_allocated(I, bs); ensure_allocated(I, bp);
     P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
+    P.lpt = (I->have_lpt && !(I->variant & 128)) ? 1u : 0u;
     P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
     P.ns = ns; P.np = np; P.nl = nl;
     P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
@@ -419,7 +426,15 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
         for (int a = 0; a < 3; a++) {
             P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
         }
-    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) { flags |= F_GEOM_LDS; dyn_lds = I->geom_f4 * 16; }
+    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) {
+        /* the prepared geometry is staged in LDS.  (Experiment, compiled out -- WT_OPT_MATLDS in whitted_trace.inc: for small
+         * scenes also 3 material float4 per primitive and the planes' texture rows, while the block stays within 2 KiB.) */
+        flags |= F_GEOM_LDS;
+        size_t scene_f4 = I->geom_f4;
+        const size_t with_mat = I->geom_f4 + 3 * ((size_t)ns + np) + 2 * (size_t)np;
+        if (env_int("CLWRAP_MAT_LDS", 0) && with_mat <= MAT_LDS_MAX_F4) { P.mat_lds = 1; scene_f4 = with_mat; }
+        dyn_lds = scene_f4 * 16;
+    }
 }
 
 /* one strip of a frame: rows [row0, row0 + rows) of the launch range, scheduling state in scheds[slot] */
@@ -475,6 +490,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         if (P.n_items == 0) return;
         P.tiled = (g.id_offset % g.width == 0 || g.band_stride > 1) && (P.n_items % g.width == 0) && !(I->variant & 2);
         P.rows = P.n_items / g.width;
+        P.row_offset = (uint32_t)(g.id_offset / g.width);
     } else {
         materialise_rays(I, rays);
         ensure_allocated(I, rays);
@@ -482,6 +498,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         P.rays = (const float*)rays->dptr;
         P.id_offset = I->id_offset;
         P.width = 1; P.height = 1;
+        P.unit_dirs = rays->gen_valid ? 1u : 0u;
         if (rays->gen_valid) {   /* ids (RNG seeds) follow the launch that generated the rays */
             P.id_offset = rays->gen.id_offset; P.width = rays->gen.width; P.height = rays->gen.height;
             P.band_stride = rays->gen.band_stride; P.band_phase = rays->gen.band_phase;
@@ -492,8 +509,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     if (I->counting || I->stamps) {
         if (I->counting) flags |= F_COUNT;
         if (!I->d_counters) {
-            HIP_OK(hipMalloc((void**)&I->d_counters, CLW_NUM_COUNTERS * sizeof(unsigned long long)), "Couldn't allocate device memory");
-            HIP_OK(hipMemsetAsync(I->d_counters, 0, CLW_NUM_COUNTERS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
+            HIP_OK(hipMalloc((void**)&I->d_counters, COUNTER_WORDS * sizeof(unsigned long long)), "Couldn't allocate device memory");
+            HIP_OK(hipMemsetAsync(I->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
         }
         P.counters = I->d_counters;
     }
@@ -505,7 +522,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         trows = (P.rows + 7) / 8; tpr = (P.width + 7) / 8;
         per_share = ((trows + 7) / 8) * tpr;
         grid = 8 * per_share;
-        if (I->sched && !(I->variant & 4)) {
+        if (I->sched && !(I->variant & 4) && trows <= 0xFFFEu && tpr <= 0xFFFFu) {   /* the order packs (tile row << 16 | column) */
             if (S.w != P.width || S.rows != P.rows || !S.cost[0]) {
                 S.free_all();
                 for (int i = 0; i < 2; i++) {
@@ -951,10 +968,12 @@ void clw_ext_read_counters_ex(cl_wrap* wrap, uint64_t* out, uint32_t n) {
     finish(I);
     for (uint32_t k = 0; k < n; k++) out[k] = 0;
     if (!I->d_counters) return;
-    unsigned long long h[CLW_NUM_COUNTERS];
-    HIP_OK(hipMemcpy(h, I->d_counters, sizeof h, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
-    HIP_OK(hipMemsetAsync(I->d_counters, 0, sizeof h, I->stream), "Couldn't allocate device memory");
+    std::vector<unsigned long long> h(COUNTER_WORDS);
+    HIP_OK(hipMemcpy(h.data(), I->d_counters, COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
+    HIP_OK(hipMemsetAsync(I->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
     finish(I);
+    for (size_t sh = 0; sh < CLW_STAMP_SHARDS; sh++)        /* stamp shards of the diagnostic build -> words 16.. */
+        for (int k = 0; k < 16; k++) h[16 + k] += h[CLW_NUM_COUNTERS + 16 * sh + k];
     for (uint32_t k = 0; k < n && k < CLW_NUM_COUNTERS; k++) out[k] = h[k];
 }
 void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]) { clw_ext_read_counters_ex(wrap, out, 8); }

@@ -81,6 +81,41 @@ void wprep_build(const uint8_t* spheres, uint32_t ns, const uint8_t* planes, uin
     }
 }
 
+/* ---- light / plane side table ------------------------------------------------------------------------
+ * For every chunk of three lights c and every plane p one float4 {mu0, mu1, mu2, 1/|n|}: mu_k is the signed distance of
+ * light 3c+k's centre from the plane, pulled towards zero by the light's radius and by a slack for every rounding on the
+ * way (0 when the light sphere touches or straddles the plane, or does not exist).  |mu_k| > 0 therefore means: every
+ * sample point on that light lies strictly on ONE side of the plane, at least |mu_k| away from it.  The trace kernel
+ * uses it to skip, for a whole wavefront, plane tests of shadow rays that cannot come out "blocked" (the shading point
+ * and the light are on the same side): whitted_trace.inc, wt_shadow_batch.  Pure work-skipping: the table never enters
+ * any arithmetic a pixel depends on. */
+size_t wprep_lpt_f4(uint32_t np, uint32_t nl) {
+    size_t n = (size_t)((nl + 2) / 3) * np;
+    return n <= 64 ? n : 0;                       /* big light x plane products: no table, no skipping */
+}
+void wprep_build_lpt(const uint8_t* planes, uint32_t np, const uint8_t* lights, uint32_t nl, float* out) {
+    if (!wprep_lpt_f4(np, nl)) return;
+    for (uint32_t c = 0; c < (nl + 2) / 3; c++)
+        for (uint32_t p = 0; p < np; p++) {
+            const uint8_t* pl = planes + 96 * (size_t)p;
+            double n[3] = {ldf(pl, 0), ldf(pl, 4), ldf(pl, 8)}, p0[3] = {ldf(pl, 16), ldf(pl, 20), ldf(pl, 24)};
+            double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            float* o = out + 4 * ((size_t)c * np + p);
+            for (int k = 0; k < 3; k++) {
+                o[k] = 0.0f;
+                uint32_t l = 3 * c + (uint32_t)k;
+                if (l >= nl || !(nn > 0.0) || !isfinite(nn)) continue;
+                const uint8_t* li = lights + 48 * (size_t)l;
+                double L[3] = {ldf(li, 0), ldf(li, 4), ldf(li, 8)}, r = fabs((double)ldf(li, 16));
+                double sd = ((L[0] - p0[0]) * n[0] + (L[1] - p0[1]) * n[1] + (L[2] - p0[2]) * n[2]) / nn;
+                double mag = fabs(L[0]) + fabs(L[1]) + fabs(L[2]) + fabs(p0[0]) + fabs(p0[1]) + fabs(p0[2]);
+                double mu = fabs(sd) - r * (1.0 + 1e-5) - 1e-5 * mag - 1e-30;
+                if (isfinite(mu) && mu > 0.0) o[k] = (float)(sd > 0 ? mu : -mu) * (1.0f - 1e-6f);
+            }
+            o[3] = (nn > 0.0 && isfinite(nn)) ? (float)(1.0 / nn) : 0.0f;
+        }
+}
+
 /* ---- uniform grid ---------------------------------------------------------------------------------- */
 static void sphere_cells(const uint8_t* s, const wprep_grid* g, int lo[3], int hi[3]) {
     float r = ldf(s, 16);

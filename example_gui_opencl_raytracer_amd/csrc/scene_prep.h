@@ -12,6 +12,10 @@ size_t wprep_geom_f4(uint32_t ns, uint32_t np, uint32_t nl);
 void wprep_build(const uint8_t* spheres, uint32_t ns, const uint8_t* planes, uint32_t np,
                  const uint8_t* lights, uint32_t nl, float* geom, float* ptex);
 
+/* light / plane side table (see scene_prep.c): wprep_lpt_f4 float4 entries, appended behind the geometry stream */
+size_t wprep_lpt_f4(uint32_t np, uint32_t nl);
+void wprep_build_lpt(const uint8_t* planes, uint32_t np, const uint8_t* lights, uint32_t nl, float* out);
+
 /* Uniform grid over the spheres (an acceleration structure for big scenes; it changes how many tests a ray
  * makes, never their results).  wprep_grid_plan fills `g` (bounds, resolution) and returns the number of
  * (cell, sphere) pairs; wprep_grid_fill then writes start[ncells+1], items[pairs], box[2*ns]. */

@@ -9,6 +9,9 @@
  *   geom[ns + 2p], geom[ns+2p+1]  plane p  : { nx, ny, nz, has_texture ? 1 : 0 }, { px, py, pz, 0 }
  *   geom[ns + 2np + 2l], [..+1]   light l  : { ox, oy, oz, r*r }, { lr, lg, lb, radius }
  *                                            with l* = (rgb * intensity) * (1/pi)
+ *   geom[ns + 2np + 2nl + c*np + p]  (only if lpt != 0) light chunk c, plane p: { mu0, mu1, mu2, 1/|n| } -- the signed
+ *                                            distance of the three lights of the chunk from the plane, less radius and
+ *                                            slack (scene_prep.c): lets a wave skip plane tests no shadow ray can fail
  *   ptex[2p], ptex[2p+1]          plane p  : { b0x, b0y, b0z, texture_scale }, { b1x, b1y, b1z, bits(texture_id) }
  *                                            (tangent basis of reference primitives.cl:226-236)
  * Materials stay in the raw arrays and are gathered for the winning primitive only.
@@ -18,7 +21,8 @@
 #include <stdint.h>
 
 #define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
-#define CLW_NUM_COUNTERS 32 /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex); 16.. = phase stamps of the diagnostic build */
+#define CLW_NUM_COUNTERS 32
+#define CLW_STAMP_SHARDS 1024 /* diagnostic stamp build: 16-word shards behind the counter block, summed into words 16.. on read */ /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex); 16.. = phase stamps of the diagnostic build */
 
 typedef struct {
     /* camera: the eight by-value raygen arguments (reference raygen.cl:5-8) */
@@ -30,11 +34,12 @@ typedef struct {
     uint32_t n_items;
     uint32_t tiled;        /* 1: range is whole rows -> 8x8 pixel tile per wavefront */
     uint32_t rows;         /* tiled: number of rows in the range                      */
+    uint32_t row_offset;   /* tiled: global row of the range's first row (= id_offset / width) */
     /* interleaved 8-row bands (multi-GPU load balance): local row y is global row
      * ((y/8)*band_stride + band_phase)*8 + y%8; band_stride <= 1 = contiguous range        */
     uint32_t band_stride, band_phase;
     /* cost-sorted tile dispatch (tiled mode; both nullable): tile_order[b] = tile served by workgroup b
-     * (row-major tile index, 0xFFFFFFFF = none), heaviest tiles of the previous frame first, one list per
+     * (packed: tile row << 16 | tile column; 0xFFFFFFFF = none), heaviest tiles of the previous frame first, one list per
      * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
     const uint32_t* tile_order;
     uint32_t* tile_cost;
@@ -47,6 +52,9 @@ typedef struct {
     const uint8_t* planes_raw;  /* 96-B rplane array                                  */
     uint32_t ns, np, nl;
     uint32_t geom_f4;      /* number of float4 in geom                                */
+    uint32_t unit_dirs;    /* unfused path: 1 = the ray buffer holds this library's raygen output (unit directions) */
+    uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
+    uint32_t mat_lds;      /* 1: the LDS scene block also holds the materials and texture rows (small scenes) */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
      * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =
      * sphere i's inclusive cell box, 10 bits per axis: lo = x0 | y0<<10 | z0<<20, hi likewise               */

@@ -123,8 +123,8 @@ void clw_ext_set_grid(cl_wrap* wrap, int on);
  * Pure scheduling: the image is bit-identical either way. */
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on);
 
-/* The per-tile cost table of the last tiled launch (row-major 8x8 tiles; cost = loop iterations of the tile's
- * most expensive pixel, +3 per shaded hit).  Returns the number of tiles; copies them if `capacity` suffices. */
+/* The per-tile cost table of the last tiled launch (row-major 8x8 tiles; cost = loop iterations of the tile's most expensive
+ * pixel, +3 per shaded hit; for scenes on the uniform grid: the lifetime of the tile's wavefront in units of 256 cycles).  Returns the number of tiles; copies them if `capacity` suffices. */
 uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity);
 
 /* Runs ONE device helper of the trace kernel over `n` input rows (host arrays; rows of `stride_in` / `stride_out`
@@ -149,7 +149,8 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
 
 /* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
- * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build. */
+ * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
+ * 128 no light / plane side table (every shadow ray tests every plane). */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
 /* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
