@@ -59,14 +59,21 @@ TIMING_EVERY = 8                # hipEvents around every 8th trace launch of a f
 FLOP = dict(sphere_test=34, plane_test=14, shadow_ray=40, light_shade=94, shaded_hit=73, sky=20, texel=25)
 
 
-def profiled(counter):
+def profiled(counter, kernel="wt_fast::wt_trace<4>"):
     """Per-launch mean of a rocprofv3 PMC counter for the C2 trace kernel, from the newest committed summary of this
-    same command (profiles/*_rocprof_summary.md, lines `COUNTER,value,dispatches`) -> (value, file) or None."""
+    same command (profiles/*_c2_rocprof_summary.md: one `### kernel ...` section per kernel, lines
+    `COUNTER,value,dispatches`; older summaries have a single unnamed section) -> (value, file) or None."""
     import glob
     import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.md"))):
-        m = re.search(rf"^{counter},([0-9.]+)", open(f).read(), re.M)
+        txt = open(f).read()
+        if "### kernel" in txt:
+            secs = [sec for sec in txt.split("### kernel")[1:] if kernel in sec.split("\n", 1)[0]]
+            if not secs:
+                continue
+            txt = secs[0]
+        m = re.search(rf"^{counter},([0-9.]+)", txt, re.M)
         if m:
             best = (float(m.group(1)), os.path.basename(f))
     return best
