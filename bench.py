@@ -267,7 +267,7 @@ def main():
         api.write_png(path, full, W, H)
         t_png = time.perf_counter() - t
         png = dict(path=os.path.relpath(path, ROOT), bytes=os.path.getsize(path), assemble_and_readback_s=round(t_host, 4),
-                   write_s=round(t_png, 3), note="outside the timed region: deflate level 1 of the 192 MB RGB image on one host core")
+                   write_s=round(t_png, 3), note="outside the timed region: the 192 MB RGB image deflated (level 1) band by band on the host cores (png_codec.c)")
     barrier()
 
     # ---- N = 1 extras: PCIe-inclusive frame rates, a moving camera, the strict build on the same workload

@@ -34,7 +34,7 @@ UNITS = [
     ("scene_prep.c", "c", ["-O2", "-std=c99", "-ffp-contract=off", "-Wall", "-Wextra"], ["scene_prep.h"]),
     ("host_camera.c", "c", ["-O2", "-std=c99", "-ffp-contract=off", "-Wall", "-Wextra", "-D_DEFAULT_SOURCE"],
      ["../../include/hip_wrap_ext.h", "../../include/opencl_wrap.h"]),
-    ("png_codec.c", "c", ["-O2", "-std=c99", "-Wall", "-Wextra"], ["png_codec.h"]),
+    ("png_codec.c", "c", ["-O2", "-std=c99", "-D_DEFAULT_SOURCE", "-pthread", "-Wall", "-Wextra"], ["png_codec.h"]),
 ]
 
 
@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra_devic
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     if force or _newer(lib, objs):
-        cmd = [HIPCC, "-shared", "-o", lib] + objs + ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [HIPCC, "-shared", "-o", lib] + objs + ["-lz", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -138,6 +138,25 @@ def test_png_roundtrip(tmp_path):
     assert np.array_equal(pil, back[..., :3])
 
 
+def test_png_writer_parallel_path_for_big_frames(tmp_path):
+    """Frames of >= 4 Mpixel (config C5's 8192 x 8192 output) are deflated band by band on all cores and stitched into
+    one zlib stream (png_codec.c): the file must decode to the same pixels with this library's reader AND with an
+    independent decoder, also when the last band is short."""
+    from PIL import Image
+    Image.MAX_IMAGE_PIXELS = None
+    rng = np.random.default_rng(7)
+    for (w, h) in ((2048, 2048), (4096, 1024 + 77)):
+        y, x = np.mgrid[0:h, 0:w]
+        img = (((x * 255 // w).astype(np.uint32) << 16) | ((y * 255 // h).astype(np.uint32) << 8)
+               | (rng.integers(0, 256, (h, w), dtype=np.uint32) * (x % 64 < 8))).reshape(-1).astype(np.uint32)
+        p = str(tmp_path / f"big_{w}x{h}.png")
+        api.write_png(p, img, w, h)
+        back = api.read_png(p)
+        packed = (back[..., 0].astype(np.uint32) << 16) | (back[..., 1].astype(np.uint32) << 8) | back[..., 2]
+        assert np.array_equal(packed.reshape(-1), img)
+        assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), back[..., :3])
+
+
 def test_png_reader_accepts_filtered_files_and_rejects_non_rgb8(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(2)
