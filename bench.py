@@ -120,7 +120,8 @@ def main():
                     help="weak: 1920x1080 per GPU of a taller frame (default); strong: the fixed 1920x1080 frame in row strips")
     ap.add_argument("--config", choices=("c2", "c5"), default="c2", help="c5: 8192x8192 depth 4 in row strips + the single PNG")
     ap.add_argument("--strict", type=int, default=0, help="1: the headline itself runs the strict arithmetic build")
-    ap.add_argument("--transport", choices=("auto", "peer", "gather"), default="auto", help="how shares reach rank 0 (N > 1)")
+    ap.add_argument("--transport", choices=("auto", "peer", "gather"), default=os.environ.get("BENCH_TRANSPORT", "auto"),
+                    help="how shares reach rank 0 (N > 1): peer-mapped buffer, torch.distributed.gather, or try the first and fall back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip timing the strict build next to the fast headline")
     ap.add_argument("--own-streams", action="store_true",

@@ -136,14 +136,41 @@ class FrameGatherer:
                 ok = 0
         except Exception:
             ok = 0
-        t = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) != 1:
-            self.peer = [None, None]
-            if self.rank == 0:
-                self.parts = [None, None]
-            return False
-        return True
+        cdev = self.device if dist.get_backend() == "nccl" else "cpu"
+
+        def agreed(flag: int) -> bool:
+            t = torch.tensor([flag], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        if agreed(ok):
+            # prove the mapping before trusting it: every rank writes a pattern into its row of both slots through ITS
+            # mapping, rank 0 reads the rows back through its own pointer
+            try:
+                n = min(4096, self.px_max * 3)
+                pat = ((torch.arange(n, device=self.device, dtype=torch.int32) * 7 + self.rank * 31 + 5) % 251).to(torch.uint8)
+                for slot in (0, 1):
+                    self.peer[slot][self.rank, :n].copy_(pat)
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                ok = 0
+            dist.barrier()
+            if self.rank == 0 and ok:
+                n = min(4096, self.px_max * 3)
+                for r in range(self.world):
+                    want = ((torch.arange(n, device=self.device, dtype=torch.int32) * 7 + r * 31 + 5) % 251).to(torch.uint8)
+                    for slot in (0, 1):
+                        if not torch.equal(self.parts[slot][r, :n], want):
+                            ok = 0
+                for slot in (0, 1):
+                    self.parts[slot].zero_()
+                torch.cuda.synchronize(self.device)
+            if agreed(ok):
+                return True
+        self.peer = [None, None]
+        if self.rank == 0:
+            self.parts = [None, None]
+        return False
 
     def before_render(self, slot: int) -> None:
         """Call before tracing into the slot's framebuffer again: its previous contents must have been packed."""
