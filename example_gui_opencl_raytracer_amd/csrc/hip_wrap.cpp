@@ -491,6 +491,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         P.tiled = (g.id_offset % g.width == 0 || g.band_stride > 1) && (P.n_items % g.width == 0) && !(I->variant & 2);
         P.rows = P.n_items / g.width;
         P.row_offset = (uint32_t)(g.id_offset / g.width);
+        P.unit_dirs = P.ns <= GRID_MIN_SPHERES ? 1u : 0u;      /* primary rays are generated (and normalised) in the kernel */
     } else {
         materialise_rays(I, rays);
         ensure_allocated(I, rays);
@@ -498,7 +499,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         P.rays = (const float*)rays->dptr;
         P.id_offset = I->id_offset;
         P.width = 1; P.height = 1;
-        P.unit_dirs = rays->gen_valid ? 1u : 0u;
+        P.unit_dirs = (rays->gen_valid && P.ns <= GRID_MIN_SPHERES) ? 1u : 0u;
         if (rays->gen_valid) {   /* ids (RNG seeds) follow the launch that generated the rays */
             P.id_offset = rays->gen.id_offset; P.width = rays->gen.width; P.height = rays->gen.height;
             P.band_stride = rays->gen.band_stride; P.band_phase = rays->gen.band_phase;

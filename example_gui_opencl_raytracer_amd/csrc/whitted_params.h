@@ -52,7 +52,7 @@ typedef struct {
     const uint8_t* planes_raw;  /* 96-B rplane array                                  */
     uint32_t ns, np, nl;
     uint32_t geom_f4;      /* number of float4 in geom                                */
-    uint32_t unit_dirs;    /* unfused path: 1 = the ray buffer holds this library's raygen output (unit directions) */
+    uint32_t unit_dirs;    /* 1: ray directions are unit (this library's own rays) and the scene is small: the fast build takes a = d.d = 1 */
     uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
     uint32_t mat_lds;      /* 1: the LDS scene block also holds the materials and texture rows (small scenes) */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
