@@ -38,7 +38,7 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 
 namespace {
 
-enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32 }; /* = WT_F_* of whitted_trace.inc */
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32, F_PERSIST = 64 }; /* = WT_F_* of whitted_trace.inc */
 /* deep launches of at least OCC_TILES_PER_DEPTH x depth wavefronts take the high-occupancy flavour: the serial tail of
  * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
@@ -128,6 +128,8 @@ struct Impl {
     int async = 0;
     int variant = 0;
     int counting = 0;
+    int persist = 0;       /* CLWRAP_PERSIST=1: persistent tile-pulling launches for big tiled ranges (experiment: slower) */
+    unsigned resident_waves = 5120;   /* wave slots of the chip for this kernel: CUs x 20 */
     int stamps = 0;        /* CLWRAP_STAMPS=1: hand the counter block to the (diagnostic) stamp build of the kernel */
     uint64_t id_offset = 0;
     uint32_t band_stride = 1, band_phase = 0;
@@ -156,6 +158,8 @@ struct Impl {
         bool have[2] = {false, false};                /* order[i] holds / will hold a schedule */
         int wr = 0;                                   /* cost buffer the next trace writes */
         hipEvent_t traced = nullptr;
+        uint32_t* ctr = nullptr;                      /* persistent launches: 8 ticket counters, one per 64-byte line */
+        uint32_t ctr_total[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* what every counter holds after the launches issued so far */
         uint32_t w = 0, rows = 0;
         RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false;   /* what the newest order was built for */
         void reset() { have[0] = have[1] = false; sig_valid = false; }
@@ -167,6 +171,8 @@ struct Impl {
                 cost[i] = order[i] = nullptr; built[i] = nullptr;
             }
             if (traced) { (void)hipEventDestroy(traced); traced = nullptr; }
+            if (ctr) { (void)hipFree(ctr); ctr = nullptr; }
+            for (uint32_t& c : ctr_total) c = 0;
             reset();
         }
     };
@@ -551,9 +557,27 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
     if ((flags & F_DEEP) && !I->strict && (uint64_t)grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
+    /* Persistent launch (experiment, CLWRAP_PERSIST=1; measured slower, see whitted_trace.inc): a resident set of waves pulls
+     * the tiles from per-XCD ticket counters instead of one workgroup per tile -- for shallow launches of at least two
+     * rounds of the chip's wave slots. */
+    unsigned launch_grid = grid;
+    if (P.tiled && I->persist && !(I->variant & 256) && grid >= 2u * I->resident_waves && !(flags & (F_DEEP | F_RAYS)) && (flags & (F_GEOM_LDS | F_GRID))) {
+        if (!S.ctr) {
+            HIP_OK(hipMalloc((void**)&S.ctr, 8 * 64), "Couldn't allocate device memory");
+            HIP_OK(hipMemsetAsync(S.ctr, 0, 8 * 64, I->stream), "Couldn't allocate device memory");
+            for (uint32_t& c : S.ctr_total) c = 0;
+        }
+        launch_grid = (I->resident_waves + 7u) / 8u * 8u;
+        P.tile_ctr = S.ctr; P.per_share = per_share;
+        for (int k2 = 0; k2 < 8; k2++) {
+            P.ctr_base[k2] = S.ctr_total[k2];
+            S.ctr_total[k2] += per_share + launch_grid / 8u;      /* per_share tickets + one empty fetch per wave of the share */
+        }
+        flags |= F_PERSIST;
+    }
     LaunchTimer t(I, kid);
-    hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
-                             : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
+    hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, launch_grid, dyn_lds, I->stream)
+                             : wt_fast_launch_trace(&P, flags, launch_grid, dyn_lds, I->stream);
     if (e != hipSuccess) die("Couldn't run the kernel");
     t.done();
     if (P.tile_cost) {
@@ -683,6 +707,12 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     if (I->timing_every == 0) I->timing_every = 1;
     I->pipeline = env_int("CLWRAP_PIPELINE", 1) ? 1 : 0;
     I->stamps = env_int("CLWRAP_STAMPS", 0) ? 1 : 0;
+    I->persist = env_int("CLWRAP_PERSIST", 0) ? 1 : 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, I->device) == hipSuccess && prop.multiProcessorCount > 0)
+            I->resident_waves = (unsigned)prop.multiProcessorCount * (unsigned)env_int("CLWRAP_PERSIST_WAVES_PER_CU", 20);
+    }
     I->occ_tiles_per_depth = (unsigned)env_int("CLWRAP_OCC_TILES_PER_DEPTH", (int)OCC_TILES_PER_DEPTH);
 
     wrap->impl = I;

@@ -43,6 +43,11 @@ typedef struct {
      * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    /* persistent launches (WT_F_PERSIST): per-XCD-share ticket counters (one per 64-byte line), this launch's base value of
+     * each, and the number of tile slots per share */
+    uint32_t* tile_ctr;
+    uint32_t ctr_base[8];
+    uint32_t per_share;
     uint32_t coop_max;     /* <= this many shading lanes -> their shadow rays are spread over the wave (0 = never) */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */

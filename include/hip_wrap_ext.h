@@ -150,7 +150,8 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
 /* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
  * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
- * 128 no light / plane side table (every shadow ray tests every plane). */
+ * 128 no light / plane side table (every shadow ray tests every plane), 256 never a persistent launch (only
+ * relevant with the experiment CLWRAP_PERSIST=1: a resident set of waves pulling tiles from ticket counters; measured slower). */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
 /* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
