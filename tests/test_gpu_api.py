@@ -403,3 +403,66 @@ def test_pure_c_bench_driver(oracle, demo_scene, tex, tmp_path):
     got = (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
     want, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 96, 64), big, tex, sky, 2)
     assert (channel_diff(got, want) == 0).mean() >= 0.999
+
+
+def test_scene_arrays_are_snapshotted_until_invalidated(R, oracle, demo_scene, tex, sky):
+    """The shim prepares its geometry once per (scene buffers, counts).  A caller that owns a scene buffer on the device
+    (clw_ext_bind_device_buffer) and rewrites it in place must call clw_ext_invalidate_scene: before that the old scene is
+    still rendered, after it the new one."""
+    import torch
+    from example_gui_opencl_raytracer_amd import api
+    from example_gui_opencl_raytracer_amd.scene import RAY, Scene
+    w, h, depth = 96, 64, 4
+    sph = torch.from_numpy(np.frombuffer(demo_scene.spheres.tobytes(), np.uint8).copy()).cuda()
+    cw = api.ClWrap()
+    cw.set_depth(depth); cw.set_strict(True)
+    cam = api.perspective(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    f3 = lambda v: np.array([v[0], v[1], v[2], 0.0], np.float32)
+    for a, v in enumerate((f3(cam.im_corner), f3(cam.origin), f3(cam.up), f3(cam.right), np.float32(cam.w_factor), np.float32(cam.h_factor),
+                           np.uint32(w), np.uint32(h))):
+        cw.load_single_data(0, a, v)
+    cw.load_global_data(0, 8, None, RAY.itemsize * w * h)
+    cw.load_single_data(1, 0, cw.buffer_handle(0, 8))
+    cw.bind_device_buffer(1, 1, sph.data_ptr(), sph.numel())            # caller-owned sphere array
+    cw.load_global_data(1, 2, demo_scene.planes)
+    cw.load_global_data(1, 3, demo_scene.lights)
+    for a, n in ((4, len(demo_scene.spheres)), (5, len(demo_scene.planes)), (6, len(demo_scene.lights))):
+        cw.load_single_data(1, a, np.uint8(n))
+    cw.load_single_data(1, 7, np.uint32(w * h))
+    cw.load_images_raw(1, 8, tex); cw.load_images_raw(1, 9, sky)
+    cw.load_global_data(1, 10, None, 4 * w * h)
+
+    def frame():
+        out = np.empty(w * h, np.uint32)
+        cw.output(w * h, 0, 0, 0, 0, None)
+        cw.output(w * h, out.nbytes, 1, 1, 10, out)
+        return out
+    first = frame()
+    moved = demo_scene.spheres.copy()
+    moved["origin"][0] = (1.5, 0.5, -2.0)                       # sphere 0 moves into view
+    sph.copy_(torch.from_numpy(np.frombuffer(moved.tobytes(), np.uint8).copy()))
+    torch.cuda.synchronize()
+    assert np.array_equal(frame(), first)                       # still the snapshot
+    cw.invalidate_scene()
+    second = frame()
+    cw.release()
+    ocam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    want, _, _ = oracle.render(ocam, Scene(moved, demo_scene.planes, demo_scene.lights), tex, sky, depth)
+    assert np.array_equal(second, want) and not np.array_equal(second, first)
+
+
+def test_traced_ray_counter(R, oracle, demo_scene, tex, sky):
+    """clw_ext_read_counters_ex: word 8 = the shadow rays really traced; the reference casts 2 per light per shaded hit,
+    the kernel elides those of surfaces whose specular and diffuse coefficients are both zero (glass)."""
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    w, h, depth = 160, 120, 4
+    r = Renderer(demo_scene, tex, sky, w, h, depth=depth, strict=True)
+    r.look(**CAM)
+    r.w.enable_counters(1)
+    r.render(readback=False)
+    c = r.w.read_counters()
+    r.release()
+    cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, w, h)
+    _, _, cnt = oracle.render(cam, demo_scene, tex, sky, depth)
+    assert c["shadow_rays"] == cnt.shadow_rays and c["segments"] == cnt.segments
+    assert 0 < c["shadow_rays_traced"] < c["shadow_rays"] and c["shadow_rays_traced"] % 2 == 0
