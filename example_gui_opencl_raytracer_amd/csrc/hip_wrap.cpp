@@ -34,7 +34,7 @@ extern "C" hipError_t wt_fast_launch_unit(int, const float*, float*, unsigned, u
 extern "C" hipError_t wt_strict_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 extern "C" hipError_t wt_fast_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
 extern "C" hipError_t wt_strict_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, hipStream_t);
+extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 
 namespace {
 
@@ -161,8 +161,8 @@ struct Impl {
         uint32_t* ctr = nullptr;                      /* persistent launches: 8 ticket counters, one per 64-byte line */
         uint32_t ctr_total[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* what every counter holds after the launches issued so far */
         uint32_t w = 0, rows = 0;
-        RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false;   /* what the newest order was built for */
-        void reset() { have[0] = have[1] = false; sig_valid = false; }
+        RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false; int sig_age = 0, newest = 0; uint64_t frame = 0, newest_frame = 0;   /* what the newest order was built for, frames since */
+        void reset() { have[0] = have[1] = false; sig_valid = false; newest = 0; }
         void free_all() {
             for (int i = 0; i < 2; i++) {
                 if (cost[i]) (void)hipFree(cost[i]);
@@ -544,14 +544,20 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             P.tile_cost = S.cost[wr];
             /* the order built two frames ago is complete by now; the one built behind the previous frame may still be
              * running (waiting for it costs that frame ~15 us, once) */
-            const int rd = S.have[wr] ? wr : (S.have[wr ^ 1] ? (wr ^ 1) : -1);
+            int rd = S.have[S.newest] ? S.newest : -1;
+            if (rd >= 0 && S.frame - S.newest_frame <= 1 && S.have[rd ^ 1]) rd ^= 1;   /* a still camera ends up on the newest */
+            S.frame++;
             /* build(k-2) read cost[wr] and wrote order[wr]: it must have finished before this trace touches either */
             if (S.have[wr]) HIP_OK(hipStreamWaitEvent(I->stream, S.built[wr], 0), "Couldn't run the kernel");
             if (rd >= 0 && rd != wr) HIP_OK(hipStreamWaitEvent(I->stream, S.built[rd], 0), "Couldn't run the kernel");
             P.tile_order = rd >= 0 ? S.order[rd] : nullptr;
             /* the costs can only change when the camera, the depth or the scene did */
             sched_rebuild = !S.sig_valid || !same_raygen(g, S.sig) || S.sig_depth != I->depth || S.sig_scene != I->scene_generation;
-            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; S.sig_valid = true; }
+            if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; S.sig_valid = true; S.sig_age = 0; }
+            /* Grid builds measure a tile by its wave's lifetime, which depends on the company it ran in: the order built
+             * from the first (unsorted, often cold) frame is refined once from the first sorted one. */
+            else if ((flags & F_GRID) && S.sig_age < 2) sched_rebuild = true;
+            if (S.sig_age < 255) S.sig_age++;
         }
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -586,10 +592,10 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             if (!I->sched_stream) HIP_OK(hipStreamCreateWithFlags(&I->sched_stream, hipStreamNonBlocking), "Couldn't create a command queue for the given device");
             HIP_OK(hipEventRecord(S.traced, I->stream), "Couldn't run the kernel");
             HIP_OK(hipStreamWaitEvent(I->sched_stream, S.traced, 0), "Couldn't run the kernel");
-            if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, I->sched_stream) != hipSuccess)
+            if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, (flags & F_GRID) ? 1u : 0u, I->sched_stream) != hipSuccess)
                 die("Couldn't run the kernel");
             HIP_OK(hipEventRecord(S.built[wr], I->sched_stream), "Couldn't run the kernel");
-            S.have[wr] = true;
+            S.have[wr] = true; S.newest = wr; S.newest_frame = S.frame - 1;
         }
         S.wr = wr ^ 1;
     }

@@ -1,5 +1,5 @@
 """Where a wave of the trace kernel spends its cycles (DIAGNOSTIC build with in-kernel stamps; never the product).
-   python tools/stamp_phases.py [c2|c3|ref800] [--strict 1]
+   python tools/stamp_phases.py [c2|c3|c4|ref800] [--strict 1]
 Builds nothing: expects libopencl_wrap_hip_stamp.so (python -c "from example_gui_opencl_raytracer_amd import build; build.build(tag='_stamp', extra_device_flags=["-DWT_STAMPS=1", "-DWT_SHALLOW_WAVES=4"])")."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,9 @@ strict = "--strict" in sys.argv
 cam = pkg.CAMERA_RAYPNG
 if cfg == "c2":
     sc, W, H, depth = scene.render_map_scene(), 1920, 1080, 4
+elif cfg == "c4":
+    sc, W, H, depth = scene.sphere_grid_scene(100, 100), 1920, 1080, 4
+    cam = dict(origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
 elif cfg == "ref800":
     sc, W, H, depth = scene.render_map_scene(), 800, 600, 15
 else:
