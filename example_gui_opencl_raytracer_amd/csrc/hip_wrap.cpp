@@ -159,7 +159,7 @@ struct Impl {
         int wr = 0;                                   /* cost buffer the next trace writes */
         hipEvent_t traced = nullptr;
         uint32_t* ctr = nullptr;                      /* persistent launches: 8 ticket counters, one per 64-byte line */
-        uint32_t ctr_total[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* what every counter holds after the launches issued so far */
+        uint32_t ctr_total[8 * CLW_TILE_QUEUES] = {};       /* what every counter holds after the launches issued so far */
         uint32_t w = 0, rows = 0;
         RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false; int sig_age = 0, newest = 0; uint64_t frame = 0, newest_frame = 0;   /* what the newest order was built for, frames since */
         void reset() { have[0] = have[1] = false; sig_valid = false; newest = 0; }
@@ -476,6 +476,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     P.out = (uint32_t*)out->dptr;
     P.out_rgb = I->debug_rgb;
     P.coop_max = (I->variant & 16) ? 0u : 10u;
+    P.diag = (I->variant & 512) ? 1u : 0u;
 
     const bool fused = I->fuse && rays->gen_valid;
     RaygenArgs g{};
@@ -568,16 +569,18 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
      * rounds of the chip's wave slots. */
     unsigned launch_grid = grid;
     if (P.tiled && I->persist && !(I->variant & 256) && grid >= 2u * I->resident_waves && !(flags & (F_DEEP | F_RAYS)) && (flags & (F_GEOM_LDS | F_GRID))) {
+        constexpr unsigned NQ = 8 * CLW_TILE_QUEUES;
         if (!S.ctr) {
-            HIP_OK(hipMalloc((void**)&S.ctr, 8 * 64), "Couldn't allocate device memory");
-            HIP_OK(hipMemsetAsync(S.ctr, 0, 8 * 64, I->stream), "Couldn't allocate device memory");
+            HIP_OK(hipMalloc((void**)&S.ctr, NQ * 64), "Couldn't allocate device memory");        /* one 64-B line per counter */
+            HIP_OK(hipMemsetAsync(S.ctr, 0, NQ * 64, I->stream), "Couldn't allocate device memory");
             for (uint32_t& c : S.ctr_total) c = 0;
         }
         launch_grid = (I->resident_waves + 7u) / 8u * 8u;
         P.tile_ctr = S.ctr; P.per_share = per_share;
-        for (int k2 = 0; k2 < 8; k2++) {
+        for (unsigned k2 = 0; k2 < NQ; k2++) {
+            const unsigned q = k2 % CLW_TILE_QUEUES;
             P.ctr_base[k2] = S.ctr_total[k2];
-            S.ctr_total[k2] += per_share + launch_grid / 8u;      /* per_share tickets + one empty fetch per wave of the share */
+            S.ctr_total[k2] += per_share > q ? (per_share - q + CLW_TILE_QUEUES - 1u) / CLW_TILE_QUEUES : 0u;   /* one ticket per tile of the queue */
         }
         flags |= F_PERSIST;
     }

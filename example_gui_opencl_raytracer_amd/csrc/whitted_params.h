@@ -22,6 +22,7 @@
 
 #define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
 #define CLW_NUM_COUNTERS 32
+#define CLW_TILE_QUEUES 8     /* persistent launches: ticket counters (sub-queues of the tile order) per XCD share */
 #define CLW_STAMP_SHARDS 1024 /* diagnostic stamp build: 16-word shards behind the counter block, summed into words 16.. on read */ /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex); 16.. = phase stamps of the diagnostic build */
 
 typedef struct {
@@ -46,7 +47,7 @@ typedef struct {
     /* persistent launches (WT_F_PERSIST): per-XCD-share ticket counters (one per 64-byte line), this launch's base value of
      * each, and the number of tile slots per share */
     uint32_t* tile_ctr;
-    uint32_t ctr_base[8];
+    uint32_t ctr_base[8 * CLW_TILE_QUEUES];   /* persistent launches: what each ticket counter held before this launch */
     uint32_t per_share;
     uint32_t coop_max;     /* <= this many shading lanes -> their shadow rays are spread over the wave (0 = never) */
     int32_t depth;         /* reference MAX_DEPTH                                     */
@@ -60,6 +61,7 @@ typedef struct {
     uint32_t unit_dirs;    /* 1: ray directions are unit (this library's own rays) and the scene is small: the fast build takes a = d.d = 1 */
     uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
     uint32_t mat_lds;      /* 1: the LDS scene block also holds the materials and texture rows (small scenes) */
+    uint32_t diag;         /* DIAGNOSTIC builds (-DWT_TIMELINE=1) only: 1 = tile_cost receives (start << 16 | end) in 10 ns ticks, not costs */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
      * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =
      * sphere i's inclusive cell box, 10 bits per axis: lo = x0 | y0<<10 | z0<<20, hi likewise               */

@@ -16,6 +16,11 @@ tex, sky = textures.texture_layers(), textures.skybox_cross(4096)
 cam = pkg.CAMERA_RAYPNG
 if a.config == "c2":
     sc, W, H, depth = scene.render_map_scene(), 1920, 1080, 4
+elif a.config == "ref800":
+    sc, W, H, depth = scene.render_map_scene(), 800, 600, 15
+elif a.config == "c3":
+    sc, W, H, depth = scene.dielectric_field_scene(8), 4096, 4096, 8
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
 elif a.config == "c4":
     sc, W, H, depth = scene.sphere_grid_scene(100, 100), 1920, 1080, 4
     cam = dict(origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)

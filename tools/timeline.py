@@ -1,0 +1,43 @@
+"""When does each tile's wave run inside one launch?  (DIAGNOSTIC build -DWT_TIMELINE=1, variant bit 512.)
+   CLWRAP_LIB=.../libopencl_wrap_hip_tl.so python tools/timeline.py c2  -> busy wave slots per 5 % of the launch"""
+import json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import example_gui_opencl_raytracer_amd as pkg
+from example_gui_opencl_raytracer_amd import scene, textures
+from example_gui_opencl_raytracer_amd.renderer import Renderer
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+strict = "--strict" in sys.argv
+cam = pkg.CAMERA_RAYPNG
+if cfg == "c2":
+    sc, W, H, depth = scene.render_map_scene(), 1920, 1080, 4
+elif cfg == "c3":
+    sc, W, H, depth = scene.dielectric_field_scene(8), 4096, 4096, 8
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+elif cfg == "ref800":
+    sc, W, H, depth = scene.render_map_scene(), 800, 600, 15
+else:
+    sc, W, H, depth = scene.sphere_grid_scene(100, 100), 1920, 1080, 4
+    cam = dict(origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
+r = Renderer(sc, textures.texture_layers(), textures.skybox_cross(4096), W, H, depth=depth, strict=strict)
+r.look(**cam)
+for _ in range(6):
+    r.render(readback=False)
+r.w.sync()
+r.w.set_variant(512)
+r.w.timing_reset(); r.render(readback=False); r.w.sync(); n, ms = r.w.timing_get(1)
+c = r.w.read_tile_costs().astype(np.int64)
+start, end = c >> 16, c & 0xFFFF
+t0 = start.min() if (start.max() - start.min()) < 32768 else ((start + 32768) & 0xFFFF).min() - 32768
+s = (start - t0) & 0xFFFF
+e = (end - t0) & 0xFFFF
+span = int(e.max())
+edges = np.linspace(0, span, 21)
+busy = [int(((s <= x) & (e > x)).sum()) for x in (edges[:-1] + edges[1:]) / 2]
+dur = e - s
+print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), span_us=span / 100.0, tiles=int(c.size),
+                      mean_wave_us=round(float(dur.mean()) / 100, 2), max_wave_us=float(dur.max()) / 100,
+                      last_start_us=float(s.max()) / 100, busy_waves_per_5pct=busy,
+                      mean_busy=round(float(dur.sum()) / max(span, 1), 1))))
+r.release()
