@@ -378,7 +378,7 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     I->grid_ok = false;
     if (ns > (uint32_t)env_int("CLWRAP_GRID_MIN", (int)GRID_MIN_SPHERES)) {   /* CLWRAP_GRID_MIN: tuning knob */
         const char* dens = getenv("CLWRAP_GRID_DENSITY");   /* tuning knob: average spheres per cell */
-        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 1.4f, &I->grid);
+        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 1.6f, &I->grid);
         if (pairs <= GRID_MAX_PAIRS) {
             std::vector<uint32_t> st((size_t)I->grid.ncells + 1), it(pairs ? pairs : 1), bx(2 * (size_t)ns);
             wprep_grid_fill(hs, ns, &I->grid, st.data(), it.data(), bx.data());

@@ -145,13 +145,17 @@ size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep
     for (int a = 0; a < 3; a++) { ext[a] = mx[a] - mn[a]; if (ext[a] > big) big = ext[a]; }
     if (!(big > 0.0f)) big = 1.0f;
     for (int a = 0; a < 3; a++) {
-        float pad = 1e-2f * big + 1e-3f;        /* every sphere lies strictly inside the grid bounds */
+        /* every sphere lies strictly inside the grid bounds -- by a margin of ITS axis (sphere_cells pads by 1e-3 cell + 1e-5 of the
+         * coordinate): a flat field of spheres (C4: 100 x 0.6 x 100) must not get a slab of empty space above it that every rising
+         * shadow ray then walks through, cell by cell, testing the spheres below it (the margin used to be 1 % of the LARGEST extent:
+         * 1.0 above a layer 0.6 thick; 9.5 -> 5 cells per shadow ray at C4) */
+        float pad = 1e-2f * ext[a] + 2e-5f * fmaxf(fabsf(mn[a]), fabsf(mx[a])) + 1e-3f;
         mn[a] -= pad; mx[a] += pad; ext[a] = mx[a] - mn[a];
         vol *= ext[a];
     }
     /* cubic cells about one mean sphere diameter wide (finer cells make every sphere span several of them, coarser
      * ones put several spheres in a cell), kept between 1/8 and 4 spheres per cell on average; `density` scales
-     * the side (tuning knob; the shim passes 1.4); 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
+     * the side (tuning knob; the shim passes 1.6); 1..1024 cells per axis (10-bit cell boxes), <= 2^22 cells */
     double diam = 0.0;
     for (uint32_t i = 0; i < ns; i++) diam += 2.0 * ldf(spheres + 96 * (size_t)i, 16);
     diam /= (double)(ns ? ns : 1);
