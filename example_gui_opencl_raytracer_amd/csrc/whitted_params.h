@@ -61,7 +61,7 @@ typedef struct {
     uint32_t unit_dirs;    /* 1: ray directions are unit (this library's own rays) and the scene is small: the fast build takes a = d.d = 1 */
     uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
     uint32_t mat_lds;      /* 1: the LDS scene block also holds the materials and texture rows (small scenes) */
-    uint32_t diag;         /* DIAGNOSTIC builds (-DWT_TIMELINE=1) only: 1 = tile_cost receives (start << 16 | end) in 10 ns ticks, not costs */
+    uint32_t diag;         /* DIAGNOSTIC builds (-DWT_TIMELINE=1) only: 1 + s = tile_cost receives (start << 16 | end) in ticks of 10 ns << s, not costs */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
      * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =
      * sphere i's inclusive cell box, 10 bits per axis: lo = x0 | y0<<10 | z0<<20, hi likewise               */

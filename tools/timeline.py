@@ -8,6 +8,8 @@ import example_gui_opencl_raytracer_amd as pkg
 from example_gui_opencl_raytracer_amd import scene, textures
 from example_gui_opencl_raytracer_amd.renderer import Renderer
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+shift = int(os.environ.get("CLWRAP_TIMELINE_SHIFT", "0"))      # ticks of 10 ns << shift (16 bits per stamp: 655 us at shift 0)
+tick_us = 0.01 * (1 << shift)
 strict = "--strict" in sys.argv
 cam = pkg.CAMERA_RAYPNG
 if cfg == "c2":
@@ -36,8 +38,8 @@ span = int(e.max())
 edges = np.linspace(0, span, 21)
 busy = [int(((s <= x) & (e > x)).sum()) for x in (edges[:-1] + edges[1:]) / 2]
 dur = e - s
-print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), span_us=span / 100.0, tiles=int(c.size),
-                      mean_wave_us=round(float(dur.mean()) / 100, 2), max_wave_us=float(dur.max()) / 100,
-                      last_start_us=float(s.max()) / 100, busy_waves_per_5pct=busy,
+print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), span_us=round(span * tick_us, 2), tiles=int(c.size),
+                      mean_wave_us=round(float(dur.mean()) * tick_us, 2), max_wave_us=round(float(dur.max()) * tick_us, 2),
+                      last_start_us=round(float(s.max()) * tick_us, 2), busy_waves_per_5pct=busy,
                       mean_busy=round(float(dur.sum()) / max(span, 1), 1))))
 r.release()
