@@ -476,7 +476,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     P.out = (uint32_t*)out->dptr;
     P.out_rgb = I->debug_rgb;
     P.coop_max = (I->variant & 16) ? 0u : 10u;
-    P.diag = (I->variant & 512) ? 1u + (uint32_t)env_int("CLWRAP_TIMELINE_SHIFT", 0) : 0u;
+    P.diag = (I->variant & 512) ? (env_int("CLWRAP_TIMELINE_EDGES", 0) ? 255u + (uint32_t)env_int("CLWRAP_TIMELINE_EDGES", 0) : 1u + (uint32_t)env_int("CLWRAP_TIMELINE_SHIFT", 0)) : 0u;
 
     const bool fused = I->fuse && rays->gen_valid;
     RaygenArgs g{};

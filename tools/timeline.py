@@ -30,6 +30,17 @@ r.w.sync()
 r.w.set_variant(512)
 r.w.timing_reset(); r.render(readback=False); r.w.sync(); n, ms = r.w.timing_get(1)
 c = r.w.read_tile_costs().astype(np.int64)
+if os.environ.get("CLWRAP_TIMELINE_EDGES") == "2":   # the prologue in three parts: staging | tile and pixel mapping | primary ray + loop set-up
+    a, b_, c_ = (c >> 22) * 0.01, ((c >> 11) & 2047) * 0.01, (c & 2047) * 0.01
+    print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), staging_us=round(float(a.mean()), 2), mapping_us=round(float(b_.mean()), 2), primary_us=round(float(c_.mean()), 2))))
+    r.release()
+    sys.exit(0)
+if os.environ.get("CLWRAP_TIMELINE_EDGES"):      # (prologue << 16 | epilogue) per tile instead of (start, end)
+    pro, epi = (c >> 16) * 0.01, (c & 0xFFFF) * 0.01
+    print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), prologue_us=dict(mean=round(float(pro.mean()), 2), p50=round(float(np.median(pro)), 2), p99=round(float(np.percentile(pro, 99)), 2)),
+                          epilogue_us=dict(mean=round(float(epi.mean()), 2), p50=round(float(np.median(epi)), 2), p99=round(float(np.percentile(epi, 99)), 2)))))
+    r.release()
+    sys.exit(0)
 start, end = c >> 16, c & 0xFFFF
 t0 = start.min() if (start.max() - start.min()) < 32768 else ((start + 32768) & 0xFFFF).min() - 32768
 s = (start - t0) & 0xFFFF
