@@ -229,6 +229,40 @@ def test_uniform_grid_equals_linear_scan(R, oracle, tex, sky, cam, kind):
     check_exact(outs[(True, 1)], want, f"grid {kind}")
 
 
+@pytest.mark.parametrize("kind", ["opaque", "mixed"])
+def test_light_spheres_seen_through_the_grid(R, oracle, tex, sky, kind):
+    """findLightIntersection's visibility check (is an opaque sphere met before the light sphere? primitives.cl:296-318)
+    walks the grid in the big-scene build.  Big light spheres above, at the edge of and INSIDE a field of 576 spheres, seen
+    from above and grazing along the rows (where field spheres hide them, transparent ones must not): grid == linear scan
+    in both builds, strict == oracle, and the lights really are in view."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sc = scene.sphere_grid_scene(24, 24)
+    sp, li = sc.spheres.copy(), sc.lights.copy()
+    if kind == "mixed":
+        g = scene.glass()
+        for name in ("ambient", "diffuse", "specular", "shininess", "transperent", "dielectric", "n", "reflectivity"):
+            sp["material"][name][::2] = g[name]
+    li["origin"][0] = (0.0, 3.0, 12.0);  li["radius"][0] = 1.5
+    li["origin"][1] = (-11.0, 0.4, 12.0); li["radius"][1] = 0.9       # at the edge, half hidden by the first rows
+    li["origin"][2] = (0.5, 0.3, 10.5);  li["radius"][2] = 0.19       # between four spheres of the field
+    sc = scene.Scene(sp, sc.planes, li)
+    w, h, depth = 160, 100, 3
+    for cam in (GRID_CAMS[0], GRID_CAMS[3], dict(origin=(0.5, 0.3, -4.0), look=(0.0, 0.0, 1.0), fov=50.0, focal=1.0)):
+        want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth)
+        assert cnt.light_probes - cnt.segments > 50          # probes that ended ON a light sphere (no solid search after them)
+        outs = {}
+        for strict in (True, False):
+            for grid in (1, 0):
+                r = Renderer(sc, tex, sky, w, h, depth=depth, strict=strict)
+                r.w.set_grid(grid)
+                r.look(**cam)
+                outs[(strict, grid)] = r.render()
+                r.release()
+            assert np.array_equal(outs[(strict, 1)], outs[(strict, 0)]), (kind, cam, strict)
+        check_exact(outs[(True, 1)], want, f"lights through the grid, {kind}")
+
+
 def test_nan_rays_on_the_grid_path_end_like_the_linear_scan(R, oracle, tex, sky):
     """A scene of more than 256 spheres (uniform-grid build) whose rays go NaN: the camera sits at the exact centre
     of a glass sphere, so view and light directions cancel, normalize(0) = NaN poisons radiance and directions, and
