@@ -432,7 +432,7 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
         for (int a = 0; a < 3; a++) {
             P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
         }
-    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && !(I->variant & 1)) {
+    } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && ns <= GRID_MIN_SPHERES && !(I->variant & 1)) {   /* (<= 256 spheres: the LDS kernels take a = d.d = 1, see unit_dirs) */
         /* the prepared geometry is staged in LDS.  (Experiment, compiled out -- WT_OPT_MATLDS in whitted_trace.inc: for small
          * scenes also 3 material float4 per primitive and the planes' texture rows, while the block stays within 2 KiB.) */
         flags |= F_GEOM_LDS;
