@@ -552,7 +552,8 @@ def test_full_size_c4_ten_thousand_spheres_against_the_oracle(R, oracle, tex):
     check_exact(r.render(), want, "C4 strict", allow=2)
     r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.release()
     assert c["segments"] + c["shadow_rays"] == cnt.rays
-    assert c["shadow_rays_traced"] == c["shadow_rays"]            # opaque plastic everywhere: nothing is elided
+    # opaque plastic everywhere: only the rays to a light BEHIND the surface (diffuse and specular terms exactly zero) are elided
+    assert 0.9 * c["shadow_rays"] < c["shadow_rays_traced"] < c["shadow_rays"]
     r = Renderer(sc, tex, sky4k, w, h, depth=4, strict=False)      # the benchmarked build at the full size
     r.look(**cam)
     got = r.render()
