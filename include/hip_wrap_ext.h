@@ -14,7 +14,7 @@
  *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>   CLWRAP_PIPELINE=<0|1>
  * Tuning / experiment knobs (defaults are the measured optima): CLWRAP_GRID_MIN, CLWRAP_GRID_DENSITY (uniform grid),
  *   CLWRAP_OCC_TILES_PER_DEPTH (deep launches of >= this x depth tiles take the high-occupancy kernel flavour),
- *   CLWRAP_TIMING_EVERY, CLWRAP_VARIANT (bit mask of clw_ext_set_variant).
+ *   CLWRAP_TIMING_EVERY, CLWRAP_VARIANT (bit mask of clw_ext_set_variant), CLWRAP_PERSIST (experiment, see clw_ext_set_variant).
  */
 #ifndef HIP_WRAP_EXT_H
 #define HIP_WRAP_EXT_H
@@ -151,7 +151,9 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
  * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
  * 128 no light / plane side table (every shadow ray tests every plane), 256 never a persistent launch (only
- * relevant with the experiment CLWRAP_PERSIST=1: a resident set of waves pulling tiles from ticket counters; measured slower). */
+ * relevant with the experiment CLWRAP_PERSIST=1: a resident set of waves pulling tiles from ticket counters; measured slower),
+ * 512 DIAGNOSTIC builds only (-DWT_TIMELINE=1, tools/timeline.py): the tile-cost buffer receives when each tile's wave ran inside the launch
+ * (CLWRAP_TIMELINE_SHIFT = tick of 10 ns << shift; CLWRAP_TIMELINE_EDGES = 1 / 2: its prologue and epilogue instead); no effect otherwise. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
 
 /* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
