@@ -263,6 +263,46 @@ def test_light_spheres_seen_through_the_grid(R, oracle, tex, sky, kind):
         check_exact(outs[(True, 1)], want, f"lights through the grid, {kind}")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sphere_cloud_through_the_grid(R, oracle, tex, sky, seed):
+    """600 spheres scattered in a box (not a flat field): radii over a decade, a third of them glass, many overlapping, two
+    of the lights INSIDE the cloud, the camera inside it too for one view.  Grid == linear scan in both builds and strict ==
+    oracle: the per-axis bounds, the cell lists of big spheres, the paired entry loads and the light-visibility walk."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    rng = np.random.default_rng(seed)
+    base = scene.sphere_grid_scene(25, 24)                      # 600 plastic spheres: overwrite the geometry
+    sp, li = base.spheres.copy(), base.lights.copy()
+    n = len(sp)
+    sp["origin"][:, 0] = rng.uniform(-9.0, 9.0, n).astype(np.float32)
+    sp["origin"][:, 1] = rng.uniform(0.2, 7.0, n).astype(np.float32)
+    sp["origin"][:, 2] = rng.uniform(2.0, 20.0, n).astype(np.float32)
+    sp["radius"] = (0.12 * 10.0 ** rng.uniform(0.0, 1.0, n)).astype(np.float32)      # 0.12 .. 1.2
+    g = scene.glass()
+    sel = rng.random(n) < 0.33
+    for name in ("ambient", "diffuse", "specular", "shininess", "transperent", "dielectric", "n", "reflectivity"):
+        sp["material"][name][sel] = g[name]
+    li["origin"][0] = (0.0, 3.5, 11.0);  li["radius"][0] = 0.4
+    li["origin"][1] = (-4.0, 1.5, 6.0);  li["radius"][1] = 0.25
+    li["origin"][2] = (3.0, 9.0, 4.0)
+    sc = scene.Scene(sp, base.planes, li)
+    w, h, depth = 128, 96, 4
+    cams = [dict(origin=(0.0, 4.0, -6.0), look=(0.0, -0.1, 1.0), fov=80.0, focal=1.0),
+            dict(origin=(1.0, 3.0, 10.0), look=(-0.3, 0.1, 1.0), fov=100.0, focal=1.0)]          # inside the cloud
+    for cam in cams:
+        want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], cam["fov"], 1.0, w, h), sc, tex, sky, depth)
+        outs = {}
+        for strict in (True, False):
+            for grid in (1, 0):
+                r = Renderer(sc, tex, sky, w, h, depth=depth, strict=strict)
+                r.w.set_grid(grid)
+                r.look(**cam)
+                outs[(strict, grid)] = r.render()
+                r.release()
+            assert np.array_equal(outs[(strict, 1)], outs[(strict, 0)]), (seed, cam, strict)
+        check_exact(outs[(True, 1)], want, f"sphere cloud {seed}")
+
+
 def test_nan_rays_on_the_grid_path_end_like_the_linear_scan(R, oracle, tex, sky):
     """A scene of more than 256 spheres (uniform-grid build) whose rays go NaN: the camera sits at the exact centre
     of a glass sphere, so view and light directions cancel, normalize(0) = NaN poisons radiance and directions, and
