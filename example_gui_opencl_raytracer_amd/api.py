@@ -35,7 +35,7 @@ SYMBOLS = [
     "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_set_timing_every", "clw_ext_set_pipeline", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
     "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_unit", "clw_ext_set_grid", "clw_ext_set_variant",
-    "clw_ext_invalidate_scene", "clw_ext_read_counters_ex", "clw_ext_unit_scene",
+    "clw_ext_set_shadow_through", "clw_ext_invalidate_scene", "clw_ext_read_counters_ex", "clw_ext_unit_scene",
     "clw_host_perspective", "clw_host_write_png", "clw_host_write_png_rgba", "clw_host_read_png",
     "clw_host_free", "clw_ext_version",
 ]
@@ -82,6 +82,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     for name in ("clw_ext_set_strict", "clw_ext_set_fuse", "clw_ext_set_async", "clw_ext_enable_counters",
                  "clw_ext_set_variant", "clw_ext_set_tile_sched", "clw_ext_set_grid"):
         getattr(L, name).argtypes = [W, C.c_int]
+    L.clw_ext_set_shadow_through.argtypes = [W, C.c_float]
     L.clw_ext_set_id_offset.argtypes = [W, C.c_uint64]
     L.clw_ext_set_row_bands.argtypes = [W, u32, u32]
     L.clw_ext_sync.argtypes = [W]
@@ -238,6 +239,7 @@ class ClWrap:
             self.L.clw_ext_read_tile_costs(C.byref(self.w), _ptr(out), n)
         return out
 
+    def set_shadow_through(self, f): self.L.clw_ext_set_shadow_through(C.byref(self.w), float(f))
     def set_grid(self, on): self.L.clw_ext_set_grid(C.byref(self.w), int(on))
     def set_tile_sched(self, on): self.L.clw_ext_set_tile_sched(C.byref(self.w), int(on))
     def set_variant(self, v): self.L.clw_ext_set_variant(C.byref(self.w), int(v))
@@ -270,8 +272,10 @@ class ClWrap:
         self.L.clw_ext_read_counters_ex(C.byref(self.w), C.byref(out), 32)
         self.last_raw_counters = [int(x) for x in out]
         names = ["segments", "shadow_rays", "light_probes", "sky_fetches", "texel_fetches", "pushes",
-                 "lane_iters", "wave_iters_x64", "shadow_rays_traced"]
-        return dict(zip(names, [int(x) for x in out]))
+                 "lane_iters", "wave_iters_x64", "shadow_rays_traced", "lights_classified"]
+        d = dict(zip(names, [int(x) for x in out]))
+        d["vis_mismatches"] = int(out[22])
+        return d
 
     def invalidate_scene(self): self.L.clw_ext_invalidate_scene(C.byref(self.w))
 

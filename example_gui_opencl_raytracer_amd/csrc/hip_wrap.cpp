@@ -38,7 +38,7 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 
 namespace {
 
-enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32, F_PERSIST = 64 }; /* = WT_F_* of whitted_trace.inc */
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32 }; /* = WT_F_* of whitted_trace.inc */
 /* deep launches of at least OCC_TILES_PER_DEPTH x depth wavefronts take the high-occupancy flavour: the serial tail of
  * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
@@ -47,7 +47,7 @@ constexpr size_t COUNTER_WORDS = CLW_NUM_COUNTERS + 16 * (size_t)CLW_STAMP_SHARD
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
 constexpr size_t GEOM_LDS_MAX_F4 = 1024; /* <= 16 KiB of prepared geometry is staged in LDS */
-constexpr size_t MAT_LDS_MAX_F4 = 128;   /* <= 2 KiB: geometry + materials + texture rows all in LDS */
+constexpr uint32_t VIS_MAX_SPHERES = 16; /* = WT_VIS_MAX_SPHERES of whitted_trace.inc */
 constexpr int SHALLOW_LEVELS = 3;   /* DFS levels the shallow builds provide (LDS + scratch): depth <= SHALLOW_LEVELS + 1 */
 constexpr uint32_t GRID_MIN_SPHERES = 256;   /* scenes beyond the reference's one-byte counts get the uniform grid (at 64 spheres it only
                                                 wins when the cells happen to align with the spheres: 9.2-15 ms vs 10.9 ms linear) */
@@ -128,8 +128,7 @@ struct Impl {
     int async = 0;
     int variant = 0;
     int counting = 0;
-    int persist = 0;       /* CLWRAP_PERSIST=1: persistent tile-pulling launches for big tiled ranges (experiment: slower) */
-    unsigned resident_waves = 5120;   /* wave slots of the chip for this kernel: CUs x 20 */
+    float through = 0.8f;  /* primitives.cl:7 TRANSPERENT_THROUGH; CLWRAP_THROUGH / clw_ext_set_shadow_through */
     int stamps = 0;        /* CLWRAP_STAMPS=1: hand the counter block to the (diagnostic) stamp build of the kernel */
     uint64_t id_offset = 0;
     uint32_t band_stride = 1, band_phase = 0;
@@ -158,8 +157,6 @@ struct Impl {
         bool have[2] = {false, false};                /* order[i] holds / will hold a schedule */
         int wr = 0;                                   /* cost buffer the next trace writes */
         hipEvent_t traced = nullptr;
-        uint32_t* ctr = nullptr;                      /* persistent launches: 8 ticket counters, one per 64-byte line */
-        uint32_t ctr_total[8 * CLW_TILE_QUEUES] = {};       /* what every counter holds after the launches issued so far */
         uint32_t w = 0, rows = 0;
         RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false; int sig_age = 0, newest = 0; uint64_t frame = 0, newest_frame = 0;   /* what the newest order was built for, frames since */
         void reset() { have[0] = have[1] = false; sig_valid = false; newest = 0; }
@@ -171,8 +168,6 @@ struct Impl {
                 cost[i] = order[i] = nullptr; built[i] = nullptr;
             }
             if (traced) { (void)hipEventDestroy(traced); traced = nullptr; }
-            if (ctr) { (void)hipFree(ctr); ctr = nullptr; }
-            for (uint32_t& c : ctr_total) c = 0;
             reset();
         }
     };
@@ -422,8 +417,12 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
     ensure_allocated(I, bs); ensure_allocated(I, bp);
     P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
     P.lpt = (I->have_lpt && !(I->variant & 128)) ? 1u : 0u;
+    /* visibility classes of the lights (wt_light_vis): small scenes whose planes are covered by the side table; variant 256 = off,
+     * variant 1024 = verification (counting build: classify AND trace, disagreements in counter word 22) */
+    P.vis = (ns <= VIS_MAX_SPHERES && (np == 0 || P.lpt) && !(I->variant & 256)) ? ((I->variant & 1024) ? 2u : 1u) : 0u;
     P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
     P.ns = ns; P.np = np; P.nl = nl;
+    P.through = I->through;
     P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
     P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
@@ -433,13 +432,9 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
             P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];
         }
     } else if (I->geom_f4 <= GEOM_LDS_MAX_F4 && ns <= GRID_MIN_SPHERES && !(I->variant & 1)) {   /* (<= 256 spheres: the LDS kernels take a = d.d = 1, see unit_dirs) */
-        /* the prepared geometry is staged in LDS.  (Experiment, compiled out -- WT_OPT_MATLDS in whitted_trace.inc: for small
-         * scenes also 3 material float4 per primitive and the planes' texture rows, while the block stays within 2 KiB.) */
+        /* the prepared geometry is staged in LDS */
         flags |= F_GEOM_LDS;
-        size_t scene_f4 = I->geom_f4;
-        const size_t with_mat = I->geom_f4 + 3 * ((size_t)ns + np) + 2 * (size_t)np;
-        if (env_int("CLWRAP_MAT_LDS", 0) && with_mat <= MAT_LDS_MAX_F4) { P.mat_lds = 1; scene_f4 = with_mat; }
-        dyn_lds = scene_f4 * 16;
+        dyn_lds = I->geom_f4 * 16;
     }
 }
 
@@ -564,29 +559,9 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
     if ((flags & F_DEEP) && !I->strict && (uint64_t)grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
-    /* Persistent launch (experiment, CLWRAP_PERSIST=1; measured slower, see whitted_trace.inc): a resident set of waves pulls
-     * the tiles from per-XCD ticket counters instead of one workgroup per tile -- for shallow launches of at least two
-     * rounds of the chip's wave slots. */
-    unsigned launch_grid = grid;
-    if (P.tiled && I->persist && !(I->variant & 256) && grid >= 2u * I->resident_waves && !(flags & (F_DEEP | F_RAYS)) && (flags & (F_GEOM_LDS | F_GRID))) {
-        constexpr unsigned NQ = 8 * CLW_TILE_QUEUES;
-        if (!S.ctr) {
-            HIP_OK(hipMalloc((void**)&S.ctr, NQ * 64), "Couldn't allocate device memory");        /* one 64-B line per counter */
-            HIP_OK(hipMemsetAsync(S.ctr, 0, NQ * 64, I->stream), "Couldn't allocate device memory");
-            for (uint32_t& c : S.ctr_total) c = 0;
-        }
-        launch_grid = (I->resident_waves + 7u) / 8u * 8u;
-        P.tile_ctr = S.ctr; P.per_share = per_share;
-        for (unsigned k2 = 0; k2 < NQ; k2++) {
-            const unsigned q = k2 % CLW_TILE_QUEUES;
-            P.ctr_base[k2] = S.ctr_total[k2];
-            S.ctr_total[k2] += per_share > q ? (per_share - q + CLW_TILE_QUEUES - 1u) / CLW_TILE_QUEUES : 0u;   /* one ticket per tile of the queue */
-        }
-        flags |= F_PERSIST;
-    }
     LaunchTimer t(I, kid);
-    hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, launch_grid, dyn_lds, I->stream)
-                             : wt_fast_launch_trace(&P, flags, launch_grid, dyn_lds, I->stream);
+    hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
+                             : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
     if (e != hipSuccess) die("Couldn't run the kernel");
     t.done();
     if (P.tile_cost) {
@@ -716,12 +691,7 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     if (I->timing_every == 0) I->timing_every = 1;
     I->pipeline = env_int("CLWRAP_PIPELINE", 1) ? 1 : 0;
     I->stamps = env_int("CLWRAP_STAMPS", 0) ? 1 : 0;
-    I->persist = env_int("CLWRAP_PERSIST", 0) ? 1 : 0;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, I->device) == hipSuccess && prop.multiProcessorCount > 0)
-            I->resident_waves = (unsigned)prop.multiProcessorCount * (unsigned)env_int("CLWRAP_PERSIST_WAVES_PER_CU", 20);
-    }
+    if (const char* th = getenv("CLWRAP_THROUGH")) { if (*th) I->through = (float)atof(th); }
     I->occ_tiles_per_depth = (unsigned)env_int("CLWRAP_OCC_TILES_PER_DEPTH", (int)OCC_TILES_PER_DEPTH);
 
     wrap->impl = I;
@@ -930,6 +900,7 @@ uint32_t clw_ext_read_tile_costs(cl_wrap* wrap, uint32_t* out, uint32_t capacity
     if (out && capacity >= n) HIP_OK(hipMemcpy(out, S.cost[S.wr ^ 1], (size_t)n * 4, hipMemcpyDeviceToHost), "Failed to transfer device memory to host");
     return n;
 }
+void clw_ext_set_shadow_through(cl_wrap* wrap, float factor) { impl_of(wrap)->through = factor; }
 void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 : 0; }
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; for (auto& sc : I->scheds) sc.reset(); }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }

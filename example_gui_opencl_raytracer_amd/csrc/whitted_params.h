@@ -22,7 +22,6 @@
 
 #define CLW_MAX_DEPTH 32 /* deepest supported trace depth (hip_wrap_ext.h) */
 #define CLW_NUM_COUNTERS 32
-#define CLW_TILE_QUEUES 8     /* persistent launches: ticket counters (sub-queues of the tile order) per XCD share */
 #define CLW_STAMP_SHARDS 1024 /* diagnostic stamp build: 16-word shards behind the counter block, summed into words 16.. on read */ /* words of the device counter block (hip_wrap_ext.h: clw_ext_read_counters_ex); 16.. = phase stamps of the diagnostic build */
 
 typedef struct {
@@ -44,11 +43,6 @@ typedef struct {
      * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
     const uint32_t* tile_order;
     uint32_t* tile_cost;
-    /* persistent launches (WT_F_PERSIST): per-XCD-share ticket counters (one per 64-byte line), this launch's base value of
-     * each, and the number of tile slots per share */
-    uint32_t* tile_ctr;
-    uint32_t ctr_base[8 * CLW_TILE_QUEUES];   /* persistent launches: what each ticket counter held before this launch */
-    uint32_t per_share;
     uint32_t coop_max;     /* <= this many shading lanes -> their shadow rays are spread over the wave (0 = never) */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */
@@ -57,10 +51,12 @@ typedef struct {
     const uint8_t* spheres_raw; /* 96-B rsphere array (materials)                     */
     const uint8_t* planes_raw;  /* 96-B rplane array                                  */
     uint32_t ns, np, nl;
+    float through;         /* factor a transparent sphere applies to a shadow ray: 0.8f = reference primitives.cl:7 (clw_ext_set_shadow_through) */
     uint32_t geom_f4;      /* number of float4 in geom                                */
     uint32_t unit_dirs;    /* 1: ray directions are unit (this library's own rays) and the scene is small: the fast build takes a = d.d = 1 */
     uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
-    uint32_t mat_lds;      /* 1: the LDS scene block also holds the materials and texture rows (small scenes) */
+    uint32_t vis;          /* 1: lights are sorted into visibility classes and only the undecided ones' samples are traced (wt_light_vis);
+                              2 (counting build): classify AND trace, count disagreements in counter word 22 */
     uint32_t diag;         /* DIAGNOSTIC builds (-DWT_TIMELINE=1) only: 1 + s = tile_cost receives (start << 16 | end) in ticks of 10 ns << s, not costs */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
      * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =

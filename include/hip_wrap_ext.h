@@ -11,10 +11,10 @@
  * reference's behaviour.  Plain C ABI: pointers and sizes only.
  *
  * Environment variables read once by cl_wrap_init (same meaning as the setters):
- *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>   CLWRAP_PIPELINE=<0|1>
+ *   CLWRAP_DEPTH=<1..32>   CLWRAP_STRICT=<0|1>   CLWRAP_FUSE=<0|1>   CLWRAP_DEVICE=<ordinal>   CLWRAP_PIPELINE=<0|1>   CLWRAP_THROUGH=<float>
  * Tuning / experiment knobs (defaults are the measured optima): CLWRAP_GRID_MIN, CLWRAP_GRID_DENSITY (uniform grid),
  *   CLWRAP_OCC_TILES_PER_DEPTH (deep launches of >= this x depth tiles take the high-occupancy kernel flavour),
- *   CLWRAP_TIMING_EVERY, CLWRAP_VARIANT (bit mask of clw_ext_set_variant), CLWRAP_PERSIST (experiment, see clw_ext_set_variant).
+ *   CLWRAP_TIMING_EVERY, CLWRAP_VARIANT (bit mask of clw_ext_set_variant).
  */
 #ifndef HIP_WRAP_EXT_H
 #define HIP_WRAP_EXT_H
@@ -113,6 +113,12 @@ void clw_ext_read_counters(cl_wrap* wrap, uint64_t out[8]);
  * only written by the diagnostic stamp build of the kernel (tools/stamp_phases.py). */
 void clw_ext_read_counters_ex(cl_wrap* wrap, uint64_t* out, uint32_t n);
 
+/* The factor a transparent sphere applies to a shadow ray that passes through it: 0.8f by default, the reference's
+ * TRANSPERENT_THROUGH (primitives.cl:7, :419).  A knob because the reference's only committed output, out/scene.png, was rendered by
+ * a version of its kernels without that attenuation: with 1.0 the unchanged raypng.c driver reproduces that image (tests/
+ * test_gpu_reference_fixture.py); also CLWRAP_THROUGH=<float> in the environment of cl_wrap_init. */
+void clw_ext_set_shadow_through(cl_wrap* wrap, float factor);
+
 /* Uniform grid over the spheres (default on; built for scenes with more than 256 spheres): rays test only the
  * spheres registered in the cells they cross instead of all of them.  Same arithmetic per test, same nearest
  * hit and same shadow factor as the reference's linear scan; 0 forces the linear scan. */
@@ -150,8 +156,9 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
 /* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
  * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
- * 128 no light / plane side table (every shadow ray tests every plane), 256 never a persistent launch (only
- * relevant with the experiment CLWRAP_PERSIST=1: a resident set of waves pulling tiles from ticket counters; measured slower),
+ * 128 no light / plane side table (every shadow ray tests every plane), 256 no visibility classes (every needed shadow ray is traced),
+ * 1024 (with clw_ext_enable_counters) VERIFICATION of the visibility classes: lights are classified AND traced, counter word 9 =
+ * lights classified, word 22 = lights whose traced factors differ from their class's (must read 0),
  * 512 DIAGNOSTIC builds only (-DWT_TIMELINE=1, tools/timeline.py): the tile-cost buffer receives when each tile's wave ran inside the launch
  * (CLWRAP_TIMELINE_SHIFT = tick of 10 ns << shift; CLWRAP_TIMELINE_EDGES = 1 / 2: its prologue and epilogue instead); no effect otherwise. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);

@@ -81,12 +81,26 @@ def dilate1(m, w, h):
     return out.reshape(-1)
 
 
-def make_masks(ref, ref_fma, orc, cam, sc, tex, sky, depth):
-    """The three discontinuity masks of one frame -> (reference frame, dict of boolean arrays)."""
+def make_masks(ref, ref_fma, orc, cam, sc, tex, sky, depth, through=None):
+    """The three discontinuity masks of one frame -> (reference frame, dict of boolean arrays).
+    ref / ref_fma: the reference kernels built without / with contraction -- or None for a scene the reference's
+    one-byte counts cannot express (C4's 10 000 spheres, raytracing.cl:17): the pair is then the restatement itself,
+    liboracle.so / liboracle_fma.so."""
     w, h = cam.width, cam.height
-    a, oob = ref.render(cam, sc, tex, sky, depth)
-    b, _ = ref_fma.render(cam, sc, tex, sky, depth)
-    assert oob == 0
+    if ref is not None:
+        a, oob = ref.render(cam, sc, tex, sky, depth)
+        b, _ = ref_fma.render(cam, sc, tex, sky, depth)
+        assert oob == 0
+    else:
+        a, _, cnt = orc.render(cam, sc, tex, sky, depth)
+        ofma = Oracle(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle_fma.so"))
+        if through is not None:
+            ofma.set_transparent_through(through)
+        b, _, _ = ofma.render(cam, sc, tex, sky, depth)
+        # (float -> int conversions out of range are undefined in OpenCL C; the restatement and the HIP kernels both convert like
+        # AMD hardware does, saturating -- the count is printed, such pixels are the restatement's word against nobody's)
+        print(f"  restatement pair: oob_reads {cnt.oob_reads} int_cast_oor {cnt.int_cast_oor}", flush=True)
+    make_masks.last_agree = float((a == b).mean())     # the scene's own noise floor: two legal builds of one source
     fma = dilate1(channel_diff(a, b) > 0, w, h)
     o0, r0, _ = orc.render(cam, sc, tex, sky, depth, want_rgb=True)
     assert np.array_equal(o0, a), "the restatement must equal the reference kernels bit for bit"
@@ -97,11 +111,57 @@ def make_masks(ref, ref_fma, orc, cam, sc, tex, sky, depth):
             _, rm, _ = orc.render(shifted_camera(cam, -dx, -dy), sc, tex, sky, depth, want_rgb=True)
             with np.errstate(invalid="ignore"):
                 jit |= np.nan_to_num(np.abs(rp + rm - 2 * r0).max(1), nan=1e9) > JITTER_TAU
-    om, mar = render_margins(cam, sc, tex, sky, depth)
+    om, mar = render_margins(cam, sc, tex, sky, depth, through)
     assert np.array_equal(om, a)
     margin = (mar[:, MARGIN_SITES.index("disc")] < DISC_MARGIN) | (mar[:, MARGIN_SITES.index("cast")] < CAST_MARGIN)
     return a, dict(fma=fma, jitter=jit, margin=margin)
 
+
+
+# the synthetic BASELINE scenes (configs C3 / C4) at sizes the oracle finishes in minutes: masks + CRC only
+SCENE_FRAMES = {
+    "c3_1024x1024_d8": dict(scene=lambda: S.dielectric_field_scene(8), origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), w=1024, h=1024, depth=8, ref=True),
+    "c4_480x270_d4": dict(scene=lambda: S.sphere_grid_scene(100, 100), origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), w=480, h=270, depth=4, ref=False),
+}
+
+
+def main_scenes():
+    """tests/golden/masks_scenes.npz: the same three mask planes + CRC for the C3 / C4 scenes (python -m oracle.gen_golden scenes)."""
+    import zlib
+    orc = Oracle()
+    tex, sky = T.texture_layers(), T.skybox_cross(512)
+    masks = {}
+    for key, f in SCENE_FRAMES.items():
+        sc = f["scene"]()
+        cam = orc.camera(f["origin"], f["look"], 90.0, 1.0, f["w"], f["h"])
+        ref, ref_fma = (Reference(), Reference(REF_FMA_SO)) if f["ref"] else (None, None)
+        img, mk = make_masks(ref, ref_fma, orc, cam, sc, tex, sky, f["depth"])
+        for name, m in mk.items():
+            masks[f"{key}_{name}"] = np.packbits(m)
+        masks[f"{key}_crc32"] = np.array([zlib.crc32(img.tobytes())], np.uint32)
+        masks[f"{key}_fma_agree"] = np.array([make_masks.last_agree], np.float64)
+        un = mk["fma"] | mk["jitter"] | mk["margin"]
+        print(f"{key}: masks fma {mk['fma'].mean():.4f} jitter {mk['jitter'].mean():.4f} margin {mk['margin'].mean():.4f} union {un.mean():.4f}"
+              f"; contraction on/off builds agree on {make_masks.last_agree:.4f}", flush=True)
+    # the reference's own committed render (tests/golden/reference_scene/): 800x600, depth 15, the real assets, transparent-shadow
+    # factor 1.0 (see whitted_oracle.c wo_set_transparent_through); restatement pair, as for C4
+    from example_gui_opencl_raytracer_amd import api
+    fx = os.path.join(GOLD, "reference_scene")
+    rtex = np.stack([api.read_png(os.path.join(fx, n + ".png")) for n in ("cobblestone", "sand", "check", "grass")])   # raypng.c:74-78
+    rsky = api.read_png(os.path.join(fx, "stormydays.png"))[None]                                                      # raypng.c:80-81
+    orc.set_transparent_through(1.0)
+    cam = orc.camera(CAM["origin"], CAM["look"], 90.0, 1.0, 800, 600)
+    img, mk = make_masks(None, None, orc, cam, S.Scene.load(os.path.join(fx, "render.map")), rtex, rsky, 15, through=1.0)
+    orc.set_transparent_through(0.8)
+    key = "scene_png_800x600_d15"
+    for name, m in mk.items():
+        masks[f"{key}_{name}"] = np.packbits(m)
+    masks[f"{key}_crc32"] = np.array([zlib.crc32(img.tobytes())], np.uint32)
+    masks[f"{key}_fma_agree"] = np.array([make_masks.last_agree], np.float64)
+    un = mk["fma"] | mk["jitter"] | mk["margin"]
+    print(f"{key}: masks fma {mk['fma'].mean():.4f} jitter {mk['jitter'].mean():.4f} margin {mk['margin'].mean():.4f} union {un.mean():.4f}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, "masks_scenes.npz"), **masks)
+    print("masks_scenes.npz", os.path.getsize(os.path.join(GOLD, "masks_scenes.npz")), "bytes")
 
 
 def unit(rng, n):
@@ -253,4 +313,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_scenes() if sys.argv[1:] == ["scenes"] else main()

@@ -97,6 +97,7 @@ class Oracle:
                                     C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
         L.wo_raygen.argtypes = [C.POINTER(Camera), C.c_uint64, C.c_uint64, C.c_void_p]
         L.wo_num_threads.restype = C.c_int
+        L.wo_set_transparent_through.argtypes = [c_f]
         L.wo_intersect_sphere.restype = C.c_int
         L.wo_intersect_sphere.argtypes = [c_f * 3, c_f * 3, c_f * 3, c_f, c_fp]
         L.wo_intersect_plane.restype = C.c_int
@@ -130,6 +131,10 @@ class Oracle:
         if not ok:
             raise ValueError("rgen_perspective rejects this camera (cpu_ray.c:58-63)")
         return cam
+
+    def set_transparent_through(self, t: float) -> None:
+        """Factor a transparent sphere applies to a shadow ray (0.8 = primitives.cl:7); a process-wide setting of this library."""
+        self.lib.wo_set_transparent_through(float(t))
 
     def num_threads(self) -> int:
         return int(self.lib.wo_num_threads())
@@ -182,9 +187,11 @@ def shifted_camera(cam: Camera, dx: float, dy: float) -> Camera:
 MARGIN_SITES = ["disc", "root", "plane", "nearest", "shadow_t", "cast", "face", "tir"]   # WO_M_* of whitted_oracle.c
 
 
-def render_margins(cam: Camera, scene, tex, sky, depth):
+def render_margins(cam: Camera, scene, tex, sky, depth, through=None):
     """-> (uint32[n] frame, float32[n, 8] smallest relative decision margin per site class); diagnostic build."""
     L = C.CDLL(MARGINS_SO)
+    L.wo_set_transparent_through.argtypes = [c_f]
+    L.wo_set_transparent_through(0.8 if through is None else float(through))
     L.wo_render_margins.restype = C.c_int
     L.wo_render_margins.argtypes = [C.POINTER(Camera), C.POINTER(SceneC), C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     inp = _Inputs(scene, tex, sky)

@@ -39,6 +39,12 @@
 #define EPSILON 0.001f                 /* primitives.cl:5 */
 #define INV_PI_F 0.31830988618379067154f /* INVERSE_SQUARE_LIGHT = M_1_PI_F, primitives.cl:6 */
 #define TRANSPARENT_THROUGH 0.8f       /* primitives.cl:7 */
+/* The factor as a run-time value (same arithmetic: one float multiply): the reference's only committed output, out/scene.png,
+ * was rendered by a version of the kernels in which a transparent sphere did NOT attenuate a shadow ray (factor 1.0) -- found
+ * by a one-parameter search, tests/test_reference_fixture.py: 88.5 % of its pixels are reproduced with 0.8, 99.3 % with 1.0 -- so
+ * the known-answer test of that fixture sets 1.0; everything else runs with the source's 0.8. */
+static float wo_through = TRANSPARENT_THROUGH;
+void wo_set_transparent_through(float t) { wo_through = t; }
 #define DEFAULT_N 1.0f                 /* raytracing.cl:7 */
 #define SOFT_SHADOWS 2                 /* raytracing.cl:10 */
 
@@ -348,7 +354,7 @@ static float shadow_path(v3 to, v3 from, const wo_scene* sc, wo_counters* cnt) {
         int hit = intersect_sphere(&r, ld3(S[i].origin), S[i].radius, &_t, cnt);
         if (hit) WO_MARGIN(WO_M_SHADOW_T, _t, t);
         if (!hit || _t >= t) continue;
-        if (S[i].material.transperent) { opacity *= TRANSPARENT_THROUGH; continue; }
+        if (S[i].material.transperent) { opacity *= wo_through; continue; }
         return 0.0f;
     }
     for (uint32_t i = 0; i < sc->np; i++) {

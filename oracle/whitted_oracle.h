@@ -93,6 +93,8 @@ int   wo_find_light(const float o[3], const float d[3], const wo_scene* sc, floa
 int   wo_find_solid(const float o[3], const float d[3], const wo_scene* sc, float point[3],
                     float normal[3], void* material64);
 int   wo_num_threads(void);
+/* factor a transparent sphere applies to a shadow ray (default 0.8f = primitives.cl:7); see whitted_oracle.c */
+void  wo_set_transparent_through(float t);
 
 #ifdef __cplusplus
 }

@@ -336,6 +336,46 @@ def test_unchanged_raypng_driver_links_and_renders(oracle, demo_scene, tex, tmp_
     assert (d == 0).mean() >= 0.995 and (d <= 1).mean() >= 0.998                  # default = fast build
 
 
+@pytest.mark.skipif(not os.path.exists(REF_RAYPNG), reason="oracle/_ref/raypng_hip not built (needs /root/reference)")
+def test_unchanged_raypng_driver_reproduces_the_references_committed_render(oracle, tmp_path):
+    """The HIP path against the one OUTPUT the reference holds: out/scene.png (tests/golden/reference_scene/, see
+    tests/test_reference_fixture.py).  The reference's unchanged raypng.c runs in a scratch tree holding the reference's own
+    render.map and asset PNGs, with the transparent-shadow factor of the version that rendered the image (CLWRAP_THROUGH=1.0) --
+    first the strict build, which must ALSO equal the oracle bit for bit, then the default fast build; both are held to the bar
+    the oracle itself meets against that image (>= 99.0 % of pixels bit-equal, >= 99.5 % within 1 LSB, <= 1000 pixels more than
+    1 LSB off outside the frame's discontinuity mask)."""
+    import shutil
+    from example_gui_opencl_raytracer_amd import api
+    from test_reference_fixture import DEPTH, FIX, H, W, check_fixture_bar, fixture_stats, load_fixture
+    from test_gpu_parity import report
+    scene, tex, sky, want, mask, _ = load_fixture()
+    for d in ("scenes", "assets/bg", "out"):
+        os.makedirs(tmp_path / d)
+    shutil.copy(os.path.join(FIX, "render.map"), tmp_path / "scenes" / "render.map")
+    for n in ("cobblestone", "sand", "check", "grass"):
+        shutil.copy(os.path.join(FIX, n + ".png"), tmp_path / "assets" / (n + ".png"))
+    shutil.copy(os.path.join(FIX, "stormydays.png"), tmp_path / "assets" / "bg" / "stormydays.png")
+    try:
+        oracle.set_transparent_through(1.0)
+        orc, _, _ = oracle.render(oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H), scene, tex, sky, DEPTH)
+    finally:
+        oracle.set_transparent_through(0.8)
+    for strict in ("1", "0"):
+        env = dict(os.environ, CLWRAP_THROUGH="1.0", CLWRAP_STRICT=strict)
+        p = subprocess.run([REF_RAYPNG], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "Done, took:" in p.stdout, p.stdout + p.stderr
+        img = api.read_png(str(tmp_path / "out" / "scene.png"))
+        assert img.shape == (H, W, 4)
+        got = (img[..., 0].astype(np.uint32) << 16 | img[..., 1].astype(np.uint32) << 8 | img[..., 2]).reshape(-1)
+        st = fixture_stats(got, want, mask)
+        report(dict(test="raypng_hip vs the reference's out/scene.png", strict=int(strict), **st,
+                    differs_from_oracle=int((got != orc).sum())))
+        check_fixture_bar(st, f"raypng_hip strict={strict}")
+        if strict == "1":
+            assert (got != orc).sum() <= 2, int((got != orc).sum())      # (ocml vs glibc sinf / cosf / powf: see check_exact)
+        os.remove(tmp_path / "out" / "scene.png")
+
+
 REF_INTERACTIVE = os.path.join(ROOT, "oracle", "_ref", "rayinteractive_hip")
 
 

@@ -112,6 +112,49 @@ def test_fast_outliers_lie_on_the_discontinuity_mask(R, oracle, demo_scene, tex,
     assert (far & ~mask).sum() == 0, f"{key}: {(far & ~mask).sum()} pixels off the mask differ by more than 1e-4: {MASK_REPORT[key]}"
 
 
+@pytest.mark.parametrize("key", ["c3_1024x1024_d8", "c4_480x270_d4"])
+def test_fast_outliers_lie_on_the_discontinuity_mask_c3_c4(R, oracle, tex, sky, key):
+    """The same claim as above for the BENCHMARKED build on the scenes of configs C3 and C4, at sizes the oracle finishes in
+    seconds (tests/golden/masks_scenes.npz, oracle/gen_golden.py `scenes`): every pixel more than 1 LSB away from the oracle's
+    frame lies on the frame's discontinuity mask, and off the mask the float radiance is within 1e-4.
+    C3 (1024x1024, depth 8, 64 glass spheres): mask 13.5 % of the pixels.
+    C4 (480x270, depth 4, 10 000 spheres): the scene IS a discontinuity field at any affordable size -- spheres of a few pixels, rays
+    that pass them at up to a hundred units (b*b - 4ac of primitives.cl:181 a difference of numbers equal to 5-7 digits): the
+    mask holds 77 % of the pixels, so for this scene the sharper statement is the second one below: the fast build is no
+    further from the oracle than the oracle's own FMA-contracted build is (96.1 % of the pixels bit-equal), two legal builds
+    of one source."""
+    import os
+    import zlib
+    from conftest import GOLDEN
+    from oracle.gen_golden import SCENE_FRAMES
+    gm = dict(np.load(os.path.join(GOLDEN, "masks_scenes.npz")))
+    f = SCENE_FRAMES[key]
+    sc, w, h, depth = f["scene"](), f["w"], f["h"], f["depth"]
+    cam = dict(origin=f["origin"], look=f["look"], fov=90.0, focal=1.0)
+    want, want_rgb, _ = oracle.render(oracle.camera(f["origin"], f["look"], 90.0, 1.0, w, h), sc, tex, sky, depth, want_rgb=True)
+    assert zlib.crc32(want.tobytes()) == int(gm[key + "_crc32"][0])
+    got, rgb = gpu_frame(R, sc, tex, sky, w, h, depth, strict=False, cam=cam, rgb=True)
+    mask = frame_mask(gm, key, w * h)
+    d = channel_diff(got, want)
+    outl = d > 1
+    with np.errstate(invalid="ignore"):
+        err = np.abs(rgb - want_rgb).max(1)
+    err = np.where(np.isnan(rgb).any(1) & np.isnan(want_rgb).any(1), 0.0, np.nan_to_num(err, nan=np.inf))
+    far = err > 1e-4
+    rec = dict(mask=float(mask.mean()), exact=float((d == 0).mean()), within_1lsb=float((d <= 1).mean()), outliers=int(outl.sum()),
+               outliers_off_mask=int((outl & ~mask).sum()), rgb_far_off_mask=int((far & ~mask).sum()),
+               max_err_off_mask=float(err[~mask].max()), oracle_fma_agree=float(gm[key + "_fma_agree"][0]))
+    report(dict(test="fast vs discontinuity mask", frame=key, **rec))
+    assert (outl & ~mask).sum() == 0, rec
+    assert (far & ~mask).sum() == 0, rec
+    if key.startswith("c3"):
+        assert mask.mean() < 0.15 and rec["exact"] >= 0.995, rec
+    else:
+        assert rec["exact"] >= rec["oracle_fma_agree"] - 0.01, rec
+    strict = gpu_frame(R, sc, tex, sky, w, h, depth, strict=True, cam=cam)
+    check_exact(strict, want, f"strict {key}")
+
+
 def test_fast_float_radiance_within_1e_4(R, oracle, demo_scene, tex, sky):
     """north_star's "1e-4 per-channel float tolerance", on the optional float output."""
     w, h, depth = 320, 240, 4
@@ -373,6 +416,78 @@ def test_plane_test_skipping_is_pure_work_skipping(R, demo_scene, tex, sky, stri
         assert np.array_equal(outs[0], outs[1])
 
 
+def _vis_cases(demo_scene):
+    """Scenes for the visibility-class tests: render.map under its two driver cameras and close-ups of the shadow edges, lights
+    moved next to / inside / behind spheres and planes, glass in front of lights, and fuzz scenes."""
+    from example_gui_opencl_raytracer_amd.scene import Scene
+    from fuzz_scenes import random_scene
+    cases = [(demo_scene, CAM, 4), (demo_scene, dict(origin=(0.8, 2.5, -8.0), look=(0.0, 0.0, 1.0), fov=90.0, focal=1.0), 15),
+             (demo_scene, dict(origin=(-3.0, 0.6, 0.5), look=(1.0, 0.05, 0.3), fov=70.0, focal=1.0), 4),
+             (demo_scene, dict(origin=(1.0, 9.0, 1.0), look=(0.01, -1.0, 0.02), fov=60.0, focal=1.0), 4),
+             (demo_scene, dict(origin=(0.9, 0.7, 1.4), look=(0.3, -0.2, 1.0), fov=100.0, focal=0.5), 8)]       # inside glass sphere #2
+    lights = demo_scene.lights.copy()
+    lights["origin"][0] = (4.5, 1.12, -1.0)          # light 0 a hair above the red plastic sphere (c = (4.5, 0.5, -1), r = 0.5)
+    lights["origin"][1] = (0.8, 0.8, 1.5)            # light 1 INSIDE glass sphere #2
+    lights["origin"][2] = (-1.0, 1.0, 6.5)           # light 2 behind the blue sphere, next to the mirror wall
+    lights["radius"][2] = 0.45                       # ... and big
+    cases.append((Scene(demo_scene.spheres, demo_scene.planes, lights), CAM, 4))
+    lights = demo_scene.lights.copy()
+    lights["radius"][:] = (0.0, 1.5, 0.02)           # a point light, a huge one, a tiny one
+    cases.append((Scene(demo_scene.spheres, demo_scene.planes, lights), CAM, 4))
+    for seed in (0, 1, 2, 3, 5, 8, 9, 13, 14, 21, 23, 34):
+        cases.append(random_scene(seed))
+    return cases
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_light_visibility_classes_are_pure_work_skipping(R, demo_scene, tex, sky, strict):
+    """wt_light_vis decides the shadow samples of a light without tracing them when every ray of the light's cone has the
+    same outcome.  (1) Same bits with the classes off (variant 256).  (2) The counting build in verification mode (variant
+    1024) classifies AND traces: not one classified light may have a traced factor that differs from its class's."""
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    classified = 0
+    for sc, cam, depth in _vis_cases(demo_scene):
+        outs = []
+        for variant in (0, 256):
+            r = Renderer(sc, tex, sky, 240, 160, depth=depth, strict=strict)
+            r.w.set_variant(variant)
+            r.look(**cam)
+            outs.append(r.render())
+            r.release()
+        assert np.array_equal(outs[0], outs[1])
+        r = Renderer(sc, tex, sky, 240, 160, depth=depth, strict=strict)
+        r.w.set_variant(1024)
+        r.w.enable_counters(1)
+        r.look(**cam)
+        chk = r.render()
+        c = r.w.read_counters()
+        r.release()
+        assert np.array_equal(chk, outs[0])
+        assert c["vis_mismatches"] == 0, c
+        classified += c["lights_classified"]
+    assert classified > 100000
+    report(dict(test="visibility classes verified", strict=strict, lights_classified=classified, mismatches=0))
+
+
+def test_light_visibility_classes_verified_at_full_c2_size(R, demo_scene, tex):
+    """The same verification on the bench workload itself (1920x1080, depth 4) and on the reference's own 800x600 depth 15."""
+    from example_gui_opencl_raytracer_amd import textures
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sky4k = textures.skybox_cross(4096)
+    for (w, h, depth) in ((1920, 1080, 4), (800, 600, 15)):
+        for strict in (True, False):
+            r = Renderer(demo_scene, tex, sky4k, w, h, depth=depth, strict=strict)
+            r.w.set_variant(1024)
+            r.w.enable_counters(1)
+            r.look(**CAM)
+            r.render(readback=False)
+            c = r.w.read_counters()
+            r.release()
+            report(dict(test="visibility classes", frame=f"{w}x{h} d{depth}", strict=strict, shadow_rays=c["shadow_rays"],
+                        lights_classified=c["lights_classified"], mismatches=c["vis_mismatches"]))
+            assert c["vis_mismatches"] == 0 and 2 * c["lights_classified"] > 0.5 * c["shadow_rays"], c
+
+
 def test_cost_sorted_dispatch_is_pure_scheduling(R, demo_scene, tex, sky):
     """Frame 1 runs in the default tile order and records tile costs; frames 2+ serve each XCD's tiles
     heaviest-first.  Same bits in every case, also after the camera moves and with scheduling off."""
@@ -524,8 +639,10 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
         r.release()
         rays = c["segments"] + c["shadow_rays"]
         assert abs(rays - cnt.rays) <= (0 if strict else 2e-4 * cnt.rays)
-        # shadow rays really traced: the ones of zero-coefficient (glass) surfaces are drawn from the RNG but elided
-        assert 0.5 * c["shadow_rays"] < c["shadow_rays_traced"] <= c["shadow_rays"]
+        # shadow rays really traced: the ones of zero-coefficient (glass) surfaces are drawn from the RNG but elided, and so are
+        # those of lights whose visibility class decides their samples (wt_light_vis: 97 % of the rest on this scene)
+        assert 0 < c["shadow_rays_traced"] <= c["shadow_rays"] - 2 * c["lights_classified"]
+        assert 2 * c["lights_classified"] > 0.6 * c["shadow_rays"]
         if strict:
             assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"]) == \
                    (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches)
@@ -599,10 +716,18 @@ def test_full_size_c4_ten_thousand_spheres_against_the_oracle(R, oracle, tex):
     got = r.render()
     # This scene's own noise floor is low: shadow and reflection rays start up to 100 units from the spheres they pass, so
     # b*b and 4ac of intersect_sphere (primitives.cl:181) agree to 5-7 digits and the sign of their difference is rounding
-    # noise over much of a sphere's cross-section -- the oracle built with and without FMA contraction (two legal builds of
-    # the same source) agrees with ITSELF on 96.1 % of the pixels of this scene (tests/test_oracle_golden.py).  The strict
-    # build reproduces the oracle's rounding exactly (above); the fast build lands at that floor: measured 96.6 %.
-    report(dict(test="C4 fast", exact=check(got, want, 0.95, 0.96), within_1lsb=float((channel_diff(got, want) <= 1).mean())))
+    # noise over much of a sphere's cross-section.  The bar is what the scene itself predicts: the oracle built WITH FMA
+    # contraction (a second legal build of the same source, liboracle_fma.so) against the oracle -- the fast build must be
+    # no further from the oracle than that build is (measured: 96.6 % vs 96.1-96.5 %); the strict build reproduces the oracle's
+    # rounding exactly (above).  The discontinuity-mask form of the claim is test_fast_outliers_lie_on_the_discontinuity_mask_c3_c4.
+    import os
+    from oracle.oracle_py import HERE, Oracle
+    fma, _, _ = Oracle(os.path.join(HERE, "liboracle_fma.so")).render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky4k, 4)
+    dfma = channel_diff(fma, want)
+    floor_exact, floor_le1 = float((dfma == 0).mean()), float((dfma <= 1).mean())
+    ex = check(got, want, floor_exact - 0.005, floor_le1 - 0.005)
+    report(dict(test="C4 fast", exact=ex, within_1lsb=float((channel_diff(got, want) <= 1).mean()),
+                oracle_fma_exact=floor_exact, oracle_fma_within_1lsb=floor_le1))
     r.release()
 
 

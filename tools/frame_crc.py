@@ -22,5 +22,5 @@ r = Renderer(sc, textures.texture_layers(), textures.skybox_cross(4096), W, H, d
 r.look(**cam)
 r.render(readback=False); r.render(readback=False)
 img = r.render()
-print(cfg, "strict" if strict else "fast", "persist=" + os.environ.get("CLWRAP_PERSIST", "0"), "%08x" % zlib.crc32(img.tobytes()))
+print(cfg, "strict" if strict else "fast", "%08x" % zlib.crc32(img.tobytes()))
 r.release()
