@@ -274,7 +274,7 @@ class ClWrap:
         names = ["segments", "shadow_rays", "light_probes", "sky_fetches", "texel_fetches", "pushes",
                  "lane_iters", "wave_iters_x64", "shadow_rays_traced", "lights_classified"]
         d = dict(zip(names, [int(x) for x in out]))
-        d["vis_mismatches"] = int(out[22])
+        d["vis_mismatches"] = int(out[28])
         return d
 
     def invalidate_scene(self): self.L.clw_ext_invalidate_scene(C.byref(self.w))

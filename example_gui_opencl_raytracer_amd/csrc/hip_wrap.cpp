@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -417,14 +418,10 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
     ensure_allocated(I, bs); ensure_allocated(I, bp);
     P.geom = I->d_geom; P.ptex = I->d_ptex; P.geom_f4 = (uint32_t)I->geom_f4;
     P.lpt = (I->have_lpt && !(I->variant & 128)) ? 1u : 0u;
-    /* visibility classes of the lights (wt_light_vis): small scenes whose planes are covered by the side table; variant 256 = off,
-     * variant 1024 = verification (counting build: classify AND trace, disagreements in counter word 22) */
-    P.vis = (ns <= VIS_MAX_SPHERES && (np == 0 || P.lpt) && !(I->variant & 256)) ? ((I->variant & 1024) ? 2u : 1u) : 0u;
-    P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
-    P.ns = ns; P.np = np; P.nl = nl;
-    P.through = I->through;
-    P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
-    P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
+    /* visibility classes of the lights (wt_light_vis; compiled into the strict build's LDS-geometry kernels): small scenes whose planes are
+     * covered by the side table; variant 256 = off, variant 1024 = verification (counting build: classify AND trace, disagreements in
+     * counter word 28) */
+    P.vis = (I->strict && ns <= VIS_MAX_SPHERES && (np == 0 || P.lpt) && !(I->variant & 256)) ? ((I->variant & 1024) ? 2u : 1u) : 0u;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
         flags |= F_GRID;
         P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
@@ -509,6 +506,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         flags |= F_RAYS;
     }
     if (I->depth > SHALLOW_LEVELS + 1) flags |= F_DEEP;
+    if (!(flags & F_GEOM_LDS)) P.vis = 0;
     if (I->counting || I->stamps) {
         if (I->counting) flags |= F_COUNT;
         if (!I->d_counters) {

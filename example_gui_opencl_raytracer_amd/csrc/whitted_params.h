@@ -55,8 +55,8 @@ typedef struct {
     uint32_t geom_f4;      /* number of float4 in geom                                */
     uint32_t unit_dirs;    /* 1: ray directions are unit (this library's own rays) and the scene is small: the fast build takes a = d.d = 1 */
     uint32_t lpt;          /* 1: the light / plane side table follows the lights in geom */
-    uint32_t vis;          /* 1: lights are sorted into visibility classes and only the undecided ones' samples are traced (wt_light_vis);
-                              2 (counting build): classify AND trace, count disagreements in counter word 22 */
+    uint32_t vis;          /* strict build, small scenes: 1: lights are sorted into visibility classes (wt_light_vis) and only the samples of
+                              undecided ones are traced; 2 (counting build): classify AND trace, count disagreements in counter word 28 */
     uint32_t diag;         /* DIAGNOSTIC builds (-DWT_TIMELINE=1) only: 1 + s = tile_cost receives (start << 16 | end) in ticks of 10 ns << s, not costs */
     /* uniform grid over the spheres (big scenes only; see scene_prep.c wprep_grid_*): cell c holds
      * grid_items[grid_start[c] .. grid_start[c+1]) = sphere indices in ascending order; grid_box[2i], [2i+1] =

@@ -158,7 +158,7 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
  * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
  * 128 no light / plane side table (every shadow ray tests every plane), 256 no visibility classes (every needed shadow ray is traced),
  * 1024 (with clw_ext_enable_counters) VERIFICATION of the visibility classes: lights are classified AND traced, counter word 9 =
- * lights classified, word 22 = lights whose traced factors differ from their class's (must read 0),
+ * lights classified, word 28 = lights whose traced factors differ from their class's (must read 0),
  * 512 DIAGNOSTIC builds only (-DWT_TIMELINE=1, tools/timeline.py): the tile-cost buffer receives when each tile's wave ran inside the launch
  * (CLWRAP_TIMELINE_SHIFT = tick of 10 ns << shift; CLWRAP_TIMELINE_EDGES = 1 / 2: its prologue and epilogue instead); no effect otherwise. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);

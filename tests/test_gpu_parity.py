@@ -439,13 +439,13 @@ def _vis_cases(demo_scene):
     return cases
 
 
-@pytest.mark.parametrize("strict", [True, False])
-def test_light_visibility_classes_are_pure_work_skipping(R, demo_scene, tex, sky, strict):
-    """wt_light_vis decides the shadow samples of a light without tracing them when every ray of the light's cone has the
-    same outcome.  (1) Same bits with the classes off (variant 256).  (2) The counting build in verification mode (variant
-    1024) classifies AND traces: not one classified light may have a traced factor that differs from its class's."""
+def test_light_visibility_classes_are_pure_work_skipping(R, demo_scene, tex, sky):
+    """wt_light_vis (strict build, small scenes) decides the shadow samples of a light without tracing them when every ray of the
+    light's cone has the same outcome.  (1) Same bits with the classes off (variant 256).  (2) The counting build in verification
+    mode (variant 1024) classifies AND traces: not one classified light may have a traced factor that differs from its class's."""
     from example_gui_opencl_raytracer_amd.renderer import Renderer
     classified = 0
+    strict = True
     for sc, cam, depth in _vis_cases(demo_scene):
         outs = []
         for variant in (0, 256):
@@ -475,7 +475,7 @@ def test_light_visibility_classes_verified_at_full_c2_size(R, demo_scene, tex):
     from example_gui_opencl_raytracer_amd.renderer import Renderer
     sky4k = textures.skybox_cross(4096)
     for (w, h, depth) in ((1920, 1080, 4), (800, 600, 15)):
-        for strict in (True, False):
+        for strict in (True,):
             r = Renderer(demo_scene, tex, sky4k, w, h, depth=depth, strict=strict)
             r.w.set_variant(1024)
             r.w.enable_counters(1)
@@ -640,9 +640,12 @@ def test_full_size_c2_against_the_oracle_and_ray_count(R, oracle, demo_scene, te
         rays = c["segments"] + c["shadow_rays"]
         assert abs(rays - cnt.rays) <= (0 if strict else 2e-4 * cnt.rays)
         # shadow rays really traced: the ones of zero-coefficient (glass) surfaces are drawn from the RNG but elided, and so are
-        # those of lights whose visibility class decides their samples (wt_light_vis: 97 % of the rest on this scene)
+        # (strict build) those of lights whose visibility class decides their samples (wt_light_vis: 97 % of the rest on this scene)
         assert 0 < c["shadow_rays_traced"] <= c["shadow_rays"] - 2 * c["lights_classified"]
-        assert 2 * c["lights_classified"] > 0.6 * c["shadow_rays"]
+        if strict:
+            assert 2 * c["lights_classified"] > 0.6 * c["shadow_rays"]
+        else:
+            assert c["lights_classified"] == 0 and c["shadow_rays_traced"] > 0.5 * c["shadow_rays"]
         if strict:
             assert (c["segments"], c["shadow_rays"], c["light_probes"], c["sky_fetches"]) == \
                    (cnt.segments, cnt.shadow_rays, cnt.light_probes, cnt.sky_fetches)

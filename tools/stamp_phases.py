@@ -11,6 +11,7 @@ from example_gui_opencl_raytracer_amd import scene, textures
 from example_gui_opencl_raytracer_amd.renderer import Renderer
 cfg = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "c2"
 strict = "--strict" in sys.argv
+variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0
 cam = pkg.CAMERA_RAYPNG
 if cfg == "c2":
     sc, W, H, depth = scene.render_map_scene(), 1920, 1080, 4
@@ -23,6 +24,7 @@ else:
     sc, W, H, depth = scene.dielectric_field_scene(8), 4096, 4096, 8
     cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
 r = Renderer(sc, textures.texture_layers(), textures.skybox_cross(4096), W, H, depth=depth, strict=strict)
+r.w.set_variant(variant)
 r.look(**cam)
 for _ in range(3):
     r.render(readback=False)
@@ -35,6 +37,6 @@ raw = r.w.last_raw_counters[16:]
 names = ["loop", "probe", "nearest", "resolve", "lights+samples", "shadow", "light_add", "bounce", "pop", "prolog"]
 tot = sum(raw[:10])
 waves = raw[10]
-print(json.dumps(dict(config=cfg, strict=strict, waves_per_frame=waves // frames, cycles_per_wave=round(tot / max(waves, 1)),
+print(json.dumps(dict(config=cfg, strict=strict, variant=variant, waves_per_frame=waves // frames, cycles_per_wave=round(tot / max(waves, 1)),
                       shares={n: round(v / max(tot, 1), 4) for n, v in zip(names, raw)})))
 r.release()
