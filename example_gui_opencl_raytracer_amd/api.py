@@ -41,6 +41,15 @@ SYMBOLS = [
 ]
 
 
+def library_version() -> str:
+    """clw_ext_version(): 'opencl_wrap_hip <ver> gfx950 fast+strict kernels:<sha256/16 of the device sources>'."""
+    return load_library().clw_ext_version().decode()
+
+
+def kernel_source_hash() -> str:
+    return library_version().rsplit("kernels:", 1)[-1]
+
+
 class cl_wrap(C.Structure):
     """Layout of ``struct cl_wrap`` in include/opencl_wrap.h."""
     _fields_ = [

@@ -38,6 +38,17 @@ UNITS = [
 ]
 
 
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) over the device sources and their flags: baked into the library (clw_ext_version) and written
+    next to every rocprofv3 summary, so that bench.py only quotes profiled counters of the kernels it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(set(DEVICE_DEPS + ["whitted_fast.hip", "whitted_strict.hip"])):
+        h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(UNITS[0][2]).encode())
+    return h.hexdigest()[:16]
+
+
 def _newer(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -55,6 +66,9 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", extra_devic
         opath = os.path.join(OBJ, src.rsplit(".", 1)[0] + tag + ".o")
         if src.endswith(".hip"):
             flags = flags + list(extra_device_flags)
+        if src == "hip_wrap.cpp":      # carries the hash of the kernels it is linked with
+            flags = flags + [f'-DWT_SOURCE_HASH="{kernel_source_hash()}{tag}"']
+            deps = deps + DEVICE_DEPS + ["whitted_fast.hip", "whitted_strict.hip"]
         objs.append(opath)
         dpaths = [spath, __file__] + [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
         if not force and not _newer(opath, dpaths):

@@ -98,6 +98,8 @@ struct Buffer {
     uint32_t w = 0, h = 0, layers = 0;
     std::vector<uint8_t> shadow;   /* host copy of uploaded data (scene arrays are re-read by scene prep) */
     bool gen_valid = false;        /* holds rays "generated" by a fused raygen launch */
+    bool exposed = false;          /* its device pointer was handed out (clw_ext_device_ptr) since the rays were generated: a caller may have
+                                      rewritten them in place, so they are no longer known to be this library's own unit vectors */
     bool gen_materialised = false;
     RaygenArgs gen{};
 };
@@ -422,6 +424,11 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
      * covered by the side table; variant 256 = off, variant 1024 = verification (counting build: classify AND trace, disagreements in
      * counter word 28) */
     P.vis = (I->strict && ns <= VIS_MAX_SPHERES && (np == 0 || P.lpt) && !(I->variant & 256)) ? ((I->variant & 1024) ? 2u : 1u) : 0u;
+    P.spheres_raw = (const uint8_t*)bs->dptr; P.planes_raw = (const uint8_t*)bp->dptr;
+    P.ns = ns; P.np = np; P.nl = nl;
+    P.through = I->through;
+    P.tex = (const uint32_t*)tex->dptr; P.tex_w = (int)tex->w; P.tex_h = (int)tex->h; P.tex_layers = (int)tex->layers;
+    P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
         flags |= F_GRID;
         P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
@@ -470,7 +477,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     P.coop_max = (I->variant & 16) ? 0u : 10u;
     P.diag = (I->variant & 512) ? (env_int("CLWRAP_TIMELINE_EDGES", 0) ? 255u + (uint32_t)env_int("CLWRAP_TIMELINE_EDGES", 0) : 1u + (uint32_t)env_int("CLWRAP_TIMELINE_SHIFT", 0)) : 0u;
 
-    const bool fused = I->fuse && rays->gen_valid;
+    const bool fused = I->fuse && rays->gen_valid && !rays->exposed;   /* (a buffer whose pointer was handed out is read, not regenerated) */
     RaygenArgs g{};
     if (fused) {
         g = rays->gen;
@@ -498,7 +505,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         P.rays = (const float*)rays->dptr;
         P.id_offset = I->id_offset;
         P.width = 1; P.height = 1;
-        P.unit_dirs = (rays->gen_valid && P.ns <= GRID_MIN_SPHERES) ? 1u : 0u;
+        P.unit_dirs = (rays->gen_valid && !rays->exposed && P.ns <= GRID_MIN_SPHERES) ? 1u : 0u;
         if (rays->gen_valid) {   /* ids (RNG seeds) follow the launch that generated the rays */
             P.id_offset = rays->gen.id_offset; P.width = rays->gen.width; P.height = rays->gen.height;
             P.band_stride = rays->gen.band_stride; P.band_phase = rays->gen.band_phase;
@@ -589,7 +596,7 @@ bool pipelined_output(cl_wrap* w, Impl* I, size_t array_size, size_t output_size
     Buffer* rays = nullptr;
     if (is_registered(w, kid, 0)) rays = (Buffer*)w->buffers[kid][0];
     else if (k.values[0].set && k.values[0].size == sizeof(cl_mem)) { void* h; memcpy(&h, k.values[0].bytes, sizeof h); rays = lookup_handle(I, h); }
-    if (!rays || !rays->gen_valid || !k.values[7].set || k.values[7].size != 4) return false;
+    if (!rays || !rays->gen_valid || rays->exposed || !k.values[7].set || k.values[7].size != 4) return false;
     const RaygenArgs& g = rays->gen;
     uint32_t total; memcpy(&total, k.values[7].bytes, 4);
     Buffer* out = (Buffer*)w->buffers[kid][10];
@@ -634,6 +641,7 @@ void run_raygen(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size) {
     rays->gen = g;
     rays->gen_valid = true;
     rays->gen_materialised = false;
+    rays->exposed = false;
     if (!I->fuse) {
         run_raygen_kernel(I, g, rays, kid);
         rays->gen_materialised = true;
@@ -905,7 +913,7 @@ void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = 
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
 
 void clw_ext_set_pipeline(cl_wrap* wrap, int on) { impl_of(wrap)->pipeline = on ? 1 : 0; }
-void clw_ext_set_timing_every(cl_wrap* wrap, uint32_t n) { Impl* I = impl_of(wrap); I->timing_every = n ? n : 1; I->timing_tick = 0; I->timing_on = true; }
+void clw_ext_set_timing_every(cl_wrap* wrap, uint32_t n) { Impl* I = impl_of(wrap); I->timing_every = n ? n : 1; I->timing_tick = 0; I->timing_on = n != 0; }
 
 void clw_ext_timing_reset(cl_wrap* wrap) {
     Impl* I = impl_of(wrap);
@@ -966,6 +974,7 @@ void* clw_ext_device_ptr(cl_wrap* wrap, cl_uint kernel_id, cl_uint arg_id) {
     Buffer* b = (Buffer*)wrap->buffers[kernel_id][arg_id];
     materialise_rays(I, b);
     ensure_allocated(I, b);
+    if (b->gen_valid) b->exposed = true;
     return b->dptr;
 }
 
@@ -998,6 +1007,9 @@ int clw_host_read_png(const char* path, uint32_t* width, uint32_t* height, uint8
 }
 void clw_host_free(void* p) { free(p); }
 
-const char* clw_ext_version(void) { return "opencl_wrap_hip 0.1 gfx950 fast+strict"; }
+#ifndef WT_SOURCE_HASH
+#define WT_SOURCE_HASH "unknown"
+#endif
+const char* clw_ext_version(void) { return "opencl_wrap_hip 0.2 gfx950 fast+strict kernels:" WT_SOURCE_HASH; }
 
 } /* extern "C" */

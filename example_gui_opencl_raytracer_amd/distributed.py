@@ -3,11 +3,10 @@
 The reference is single-device (one platform, one device, one queue; reference
 src/opencl_wrap.c:26-34); pixels are independent work-items (raytracing.cl:23-37,194), so
 the path shards by rows (contiguous strips, or interleaved 8-row bands for balance) with no data-path
-collective.  The one exchange is a single gather of the finished rows to rank 0 over xGMI: every rank
-stores its RGB888 share straight into rank 0's frame buffer (peer-mapped through a HIP IPC handle, one
-device-to-device copy per rank and frame) and a one-word all-reduce (RCCL, backend "nccl") tells rank 0
-the frame is complete; where peer mapping is not available the share travels by `torch.distributed.gather`
-(RCCL send/recv; gloo on CPU for the tests).  Work-item ids stay GLOBAL (renderer.Renderer /
+collective.  The one exchange is a single gather of the finished rows (packed to RGB888) to rank 0 over xGMI:
+`torch.distributed.gather` -- RCCL's gather on the "nccl" backend, gloo on CPU for the tests -- or, opt-in, every rank
+storing its share straight into rank 0's frame buffer (peer-mapped through a HIP IPC handle, one device-to-device copy
+per rank and frame, a one-word all-reduce as the completion signal).  Work-item ids stay GLOBAL (renderer.Renderer /
 clw_ext_set_id_offset / clw_ext_set_row_bands) so the assembled image is bit-identical to a single-GPU render.
 """
 from __future__ import annotations
@@ -76,10 +75,19 @@ class FrameGatherer:
     bounds a gather into one GPU.  Rank 0 keeps, per slot, one row of `px_max * 3` bytes per rank (`parts`);
     `assemble` turns that into the 0x00RRGGBB frame.
 
-    transport "peer": rank 0's `parts` are mapped into every rank through a HIP IPC handle and each rank writes its
-    row with ONE device-to-device copy over its own xGMI link -- no send/recv kernels, no staging; a one-word
-    all-reduce behind the copies is the completion signal.  transport "gather": `torch.distributed.gather`.
-    "auto" tries "peer" on GPUs and falls back to "gather" when the mapping cannot be set up."""
+    transport "gather" (alias "rccl-gather", the default): ONE `torch.distributed.gather` per frame -- on the nccl backend that is
+    RCCL's gather, north_star's "single RCCL gather of the final image over xGMI".
+    transport "peer" (opt-in; measured with two ranks on one GPU only, never yet on distinct GPUs): rank 0's `parts` are mapped into
+    every rank through a HIP IPC handle and each rank writes its row with ONE device-to-device copy over its own xGMI link -- no
+    send/recv kernels, no staging; a one-word all-reduce behind the copies is the completion signal.  It needs every process to see
+    every GPU (the mapping opens rank 0's allocation on rank 0's device); where it cannot be set up the constructor RAISES for "peer"
+    and falls back to "gather" only for "auto".
+
+    Slot reuse.  Frame k+2 reuses the slot of frame k.  A rank must not overwrite rank 0's `parts[slot]` while rank 0 still reads
+    frame k out of it: with "gather" rank 0 issues the receiving collective itself, behind the consumer's `release(slot)` event; with "peer"
+    the writers wait for the completion all-reduce of frame k+1, and rank 0 joins that all-reduce only behind `release(slot)` of
+    frame k -- the event a per-frame consumer records after its last read of `parts[slot]` (`assemble` records it itself).  A consumer
+    that never reads intermediate frames (bench.py) calls nothing and nobody waits."""
 
     def __init__(self, width: int, height: int, rank: int, world: int, device, layout: str = "bands",
                  transport: str = "auto", staged_on_cpu: bool = False):
@@ -102,7 +110,10 @@ class FrameGatherer:
         self.flag = torch.zeros(1, dtype=torch.int32, device=cdev)
         self.parts = [None, None]             # rank 0: uint8 [world, px_max * 3] per slot
         self.peer = [None, None]              # every rank (peer transport): rank 0's `parts`, mapped here
+        self.consumed = [None, None]          # rank 0, peer transport: recorded after the consumer's last read of parts[slot]
         self.transport = "gather"
+        if transport == "rccl-gather":
+            transport = "gather"
         if world > 1:
             if transport in ("auto", "peer") and self.device.type == "cuda":
                 self.transport = "peer" if self._map_peer_buffers() else "gather"
@@ -197,9 +208,14 @@ class FrameGatherer:
                 self.packed[slot][:n3].view(-1, 3).copy_(bgr)
                 self.ev_packed[slot].record(self.comm)
                 if self.transport == "peer":
+                    self._wait(slot ^ 1)                          # frame k-1 complete everywhere => rank 0 has released frame k-2's slot (this one)
+                    if self.rank == 0 and self.consumed[slot ^ 1] is not None:
+                        self.comm.wait_event(self.consumed[slot ^ 1])   # rank 0 joins frame k's signal only behind its reads of frame k-1... see release()
                     self.peer[slot][self.rank, :n3].copy_(self.packed[slot][:n3], non_blocking=True)   # one copy over this rank's link
                     self.pending[slot] = dist.all_reduce(self.flag, async_op=True)                     # "frame complete" for rank 0
                 else:
+                    if self.rank == 0 and self.consumed[slot] is not None:
+                        self.comm.wait_event(self.consumed[slot])     # the consumer's reads of frame k-2 (same slot) come first
                     self.pending[slot] = dist.gather(self.packed[slot], gather_list=list(self.parts[slot]) if self.rank == 0 else None,
                                                      dst=0, async_op=True)
             self.used[slot] = True
@@ -207,6 +223,9 @@ class FrameGatherer:
             self._wait(slot)
             self.packed[slot][:n3].view(-1, 3).copy_(bgr.cpu() if share.is_cuda else bgr)
             if self.transport == "peer":                          # rehearsal on one GPU: the mapping is real, the signal is gloo's
+                self._wait(slot ^ 1)                              # see the GPU branch: the other slot's frame is complete everywhere
+                if self.rank == 0 and self.consumed[slot ^ 1] is not None:
+                    self.consumed[slot ^ 1].synchronize()
                 self.peer[slot][self.rank, :n3].copy_(self.packed[slot][:n3].to(self.device))
                 torch.cuda.synchronize(self.device)
                 self.pending[slot] = dist.all_reduce(self.flag, async_op=True)
@@ -225,6 +244,24 @@ class FrameGatherer:
         if self.on_gpu:
             self.comm.synchronize()
 
+    def complete(self, slot: int) -> None:
+        """Rank 0, per-frame consumer: block until the frame submitted into `slot` has arrived in `parts[slot]`."""
+        if self.on_gpu:
+            with torch.cuda.stream(self.comm):
+                self._wait(slot)
+            self.comm.synchronize()
+        else:
+            self._wait(slot)
+
+    def release(self, slot: int) -> None:
+        """Rank 0: the consumer's reads of `parts[slot]` (queued on the current stream) are the last ones: the ranks may overwrite
+        it from the frame after next on.  With the peer transport rank 0 signals "frame k+1 complete" only behind this point, and
+        the writers of frame k+2 wait for that signal (submit)."""
+        if self.rank == 0 and self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.consumed[slot] = ev
+
     def assemble_rgb(self, slot: int) -> torch.Tensor:
         """Rank 0: the last frame gathered into `slot` as uint8 [height * width, 3] in B, G, R byte order."""
         assert self.rank == 0
@@ -237,7 +274,9 @@ class FrameGatherer:
     def assemble(self, slot: int) -> torch.Tensor:
         """Rank 0: the full frame as int32 [height * width] (0x00RRGGBB) of the last frame gathered into `slot`."""
         rgb = self.assemble_rgb(slot).to(torch.int32)
-        return (rgb[:, 2] << 16) | (rgb[:, 1] << 8) | rgb[:, 0]
+        out = (rgb[:, 2] << 16) | (rgb[:, 1] << 8) | rgb[:, 0]
+        self.release(slot)
+        return out
 
 
 class BandGatherer(FrameGatherer):

@@ -74,9 +74,10 @@ void clw_ext_timing_get(cl_wrap* wrap, cl_uint kernel_id, uint32_t* launches, do
  * loss there). */
 void clw_ext_set_pipeline(cl_wrap* wrap, int on);
 
-/* Record the events around every n-th launch only (default 1 = every launch; env CLWRAP_TIMING_EVERY).  An event
- * record between two kernels of a stream keeps the second from being dispatched while the first drains: at
- * 1920x1080 depth 4 that is 5 us per 125-us frame, so a throughput loop samples (bench.py: every 8th launch). */
+/* Record the events around every n-th launch only (default 1 = every launch; env CLWRAP_TIMING_EVERY; 0 = none until the next
+ * clw_ext_timing_reset / clw_ext_set_timing_every).  An event record between two kernels of a stream keeps the second from being
+ * dispatched while the first drains: at 1920x1080 depth 4 that is 5 us per 125-us frame, so bench.py times its throughput loops
+ * with no events at all and measures the kernel in one extra pass with events around every launch. */
 void clw_ext_set_timing_every(cl_wrap* wrap, uint32_t n);
 
 /* Texture / skybox layer stack from memory instead of PNG files: `rgba` is

@@ -136,3 +136,43 @@ def test_unequal_row_strips_through_the_frame_gatherer(oracle, demo_scene, tex, 
     cam = oracle.camera(CAM["origin"], CAM["look"], 90.0, 1.0, W, H)
     want, _, _ = oracle.render(cam, demo_scene, tex, sky, DEPTH)
     assert np.array_equal(np.load(out), want)
+
+
+def _consumer_worker(rank, world, port, out_path):
+    """Every frame is DIFFERENT and rank 0 consumes every frame (complete -> assemble -> compare) while the ranks keep submitting:
+    the slot-reuse rule of FrameGatherer (release / the consumer's event before a slot is overwritten)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from example_gui_opencl_raytracer_amd import distributed as D
+    from example_gui_opencl_raytracer_amd.renderer import strip_rows
+    D.init_process_group("gloo")
+    gat = D.FrameGatherer(W, H, rank, world, torch.device("cpu"), layout="strips", transport="rccl-gather")
+    assert gat.transport == "gather"
+    r0, rows = strip_rows(H, world, rank)
+
+    def frame_pixels(k):         # 0x00RRGGBB words that depend on the frame and on the GLOBAL pixel index
+        idx = np.arange(W * H, dtype=np.int64)
+        return ((idx * 2654435761 + k * 40503) & 0xFFFFFF).astype(np.int32)
+
+    bad = 0
+    for k in range(7):
+        s = k & 1
+        gat.before_render(s)
+        gat.submit(s, torch.from_numpy(frame_pixels(k)[r0 * W:(r0 + rows) * W].copy()))
+        if rank == 0:
+            gat.complete(s)
+            bad += int(not np.array_equal(gat.assemble(s).numpy(), frame_pixels(k)))
+    gat.drain()
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([bad]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_frame_consumer_sees_every_frame_whole(tmp_path, world):
+    out = str(tmp_path / f"consumer_{world}.npy")
+    mp.spawn(_consumer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert int(np.load(out)[0]) == 0

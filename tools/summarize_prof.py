@@ -5,7 +5,10 @@ resources and the per-dispatch mean of every PMC counter (each pass was its own 
 import collections, csv, glob, os, re, sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
-out = []
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from example_gui_opencl_raytracer_amd import api
+# which kernels were profiled: bench.py only quotes a summary whose hash names the kernels of the library it has loaded
+out = [f"kernel_source_sha256_16: {api.kernel_source_hash()}\nlibrary: {api.library_version()}\n\n"]
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     out.append(f"## rocprofv3 --kernel-trace --stats ({os.path.basename(f)})\n")
     out.append("".join(l for l in open(f) if "at::native" not in l))
