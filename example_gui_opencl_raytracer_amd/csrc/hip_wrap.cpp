@@ -39,7 +39,7 @@ extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned,
 
 namespace {
 
-enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32 }; /* = WT_F_* of whitted_trace.inc */
+enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC = 32, F_D8 = 64, F_D16 = 128 }; /* = WT_F_* of whitted_trace.inc */
 /* deep launches of at least OCC_TILES_PER_DEPTH x depth wavefronts take the high-occupancy flavour: the serial tail of
  * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
@@ -564,6 +564,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
     if ((flags & F_DEEP) && !I->strict && (uint64_t)grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
+    /* deep launches: the scratch part of the DFS stack is sized for the launch's depth (7 / 15 / 31 parents) */
+    if ((flags & F_DEEP) && !(flags & F_COUNT) && !(I->variant & 2048)) flags |= I->depth <= 8 ? F_D8 : (I->depth <= 16 ? F_D16 : 0);
     LaunchTimer t(I, kid);
     hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);

@@ -158,6 +158,7 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
  * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
  * 128 no light / plane side table (every shadow ray tests every plane), 256 no visibility classes (every needed shadow ray is traced),
+ * 2048 deep launches always carry the full-depth (31-parent) scratch stack instead of one sized for their depth,
  * 1024 (with clw_ext_enable_counters) VERIFICATION of the visibility classes: lights are classified AND traced, counter word 9 =
  * lights classified, word 28 = lights whose traced factors differ from their class's (must read 0),
  * 512 DIAGNOSTIC builds only (-DWT_TIMELINE=1, tools/timeline.py): the tile-cost buffer receives when each tile's wave ran inside the launch

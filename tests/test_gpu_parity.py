@@ -663,14 +663,40 @@ def test_large_frame_is_deterministic_and_tile_order_free(R, tex, sky):
     sc = scene.dielectric_field_scene(8)
     cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
     outs = []
-    for variant in (0, 0, 2, 64):
+    # (2048: the scratch part of the DFS stack sized for CLW_MAX_DEPTH instead of for this depth)
+    for variant in (0, 0, 2, 64, 2048):
         r = Renderer(sc, tex, sky, 4096, 4096, depth=8, strict=False)
         r.w.set_variant(variant)
         r.look(**cam)
         outs.append(r.render())
         r.release()
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert len(np.unique(outs[0])) > 1000
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_deep_refraction_trees_on_the_glass_field(R, oracle, tex, sky, strict):
+    """The DFS stack at work: glass field at depth 15 (302 rays per pixel, stacks 15 deep) and, on a smaller frame, depth 20 (1 750 rays per
+    pixel; at depth 32 the refraction trees of this scene explode).  The ordinary launch, the low-occupancy flavour of the deep build
+    (variant 64: three stack levels in LDS instead of one) and the full-depth scratch stack (variant 2048) give the same bits; the strict
+    build equals the oracle."""
+    from example_gui_opencl_raytracer_amd import scene
+    from example_gui_opencl_raytracer_amd.renderer import Renderer
+    sc = scene.dielectric_field_scene(8)
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    for depth, w, h in ((15, 192, 160), (20, 96, 80)):
+        outs = []
+        for variant in (0, 64, 2048, 64 | 2048):
+            r = Renderer(sc, tex, sky, w, h, depth=depth, strict=strict)
+            r.w.set_variant(variant)
+            r.look(**cam)
+            outs.append(r.render())
+            r.release()
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+        if strict:
+            want, _, cnt = oracle.render(oracle.camera(cam["origin"], cam["look"], 90.0, 1.0, w, h), sc, tex, sky, depth)
+            assert cnt.max_stack >= 14
+            check_exact(outs[0], want, f"glass field depth {depth}")
 
 
 # ------------------------------------------------------------ the other BASELINE.json configurations at FULL size
