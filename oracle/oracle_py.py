@@ -97,6 +97,16 @@ class Oracle:
                                     C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
         L.wo_raygen.argtypes = [C.POINTER(Camera), C.c_uint64, C.c_uint64, C.c_void_p]
         L.wo_num_threads.restype = C.c_int
+        for fn in ("wo_libm_sinf", "wo_libm_cosf"):
+            getattr(L, fn).restype = c_f
+            getattr(L, fn).argtypes = [c_f]
+        L.wo_libm_powf.restype = c_f
+        L.wo_libm_powf.argtypes = [c_f, c_f]
+        L.wo_libm_angle.restype = c_f
+        L.wo_libm_angle.argtypes = [c_f, C.c_int]
+        L.wo_trace_libm.restype = C.c_int
+        L.wo_trace_libm.argtypes = [C.POINTER(Camera), C.POINTER(SceneC), C.c_int, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_uint32]
         L.wo_set_transparent_through.argtypes = [c_f]
         L.wo_intersect_sphere.restype = C.c_int
         L.wo_intersect_sphere.argtypes = [c_f * 3, c_f * 3, c_f * 3, c_f, c_fp]
@@ -154,6 +164,20 @@ class Oracle:
         if rc:
             raise ValueError("wo_render: bad depth / id range")
         return out, rgb, cnt
+
+    def trace_libm(self, cam: Camera, scene, tex, sky, depth, pixel_id, cap=1 << 16, overrides=None):
+        """-> (packed pixel, float32 [rows, 4] = {tag, a, b, result}): the sinf / cosf / powf calls of ONE pixel and the results used
+        (tag 0: the xorshift pair of a soft-shadow sample; 1-4: sin / cos of phi and theta; 5: powf(a, b)).  `overrides`: rows of the
+        same shape whose `result` replaces glibc's for exactly these input bits (another libm's values)."""
+        inp = _Inputs(scene, tex, sky)
+        log = np.zeros((cap, 4), np.float32)
+        px = C.c_uint32(0)
+        ov = None if overrides is None or len(overrides) == 0 else np.ascontiguousarray(overrides, np.float32)
+        n = self.lib.wo_trace_libm(C.byref(cam), C.byref(inp.c), depth, int(pixel_id), C.byref(px), _p(log), cap,
+                                   _p(ov) if ov is not None else None, 0 if ov is None else len(ov))
+        if n < 0 or n > cap:
+            raise ValueError("wo_trace_libm: bad depth, or the pixel makes more libm calls than `cap`")
+        return int(px.value), log[:n].copy()
 
     def raygen(self, cam: Camera, id_begin=0, id_end=None) -> np.ndarray:
         id_end = cam.width * cam.height if id_end is None else id_end

@@ -43,6 +43,31 @@
  * was rendered by a version of the kernels in which a transparent sphere did NOT attenuate a shadow ray (factor 1.0) -- found
  * by a one-parameter search, tests/test_reference_fixture.py: 88.5 % of its pixels are reproduced with 0.8, 99.3 % with 1.0 -- so
  * the known-answer test of that fixture sets 1.0; everything else runs with the source's 0.8. */
+/* ---- libm call log and override (wo_trace_libm): which sinf / cosf / powf inputs one pixel evaluates, and with whose results.  The device
+ * libm (ocml) rounds a few per cent of all inputs one ulp away from glibc, and now and then such an ulp decides a shadow sample or an
+ * 8-bit truncation; tests/test_gpu_parity.py::pin_strict_residual uses this to PROVE that nothing else separates the strict build from
+ * this oracle: the pixel is re-traced here with the DEVICE's results substituted for glibc's and must come out as the GPU's pixel, bit for bit.
+ * Rows of four floats {tag, a, b, result}: tag 0 = the xorshift pair of one soft-shadow sample (theta = fl32(2 pi a), phi = fl32(pi b));
+ * tags 1..4 = sinf(phi), cosf(phi), sinf(theta), cosf(theta) with a = the angle; tag 5 = powf(a, b).  An override table has the same rows. */
+static __thread float* wo_libm_log = 0;
+static __thread uint32_t wo_libm_cap = 0, wo_libm_n = 0;
+static __thread const float* wo_libm_ovr = 0;
+static __thread uint32_t wo_libm_ovr_n = 0;
+static inline void wo_libm_row(float tag, float a, float b, float r) {
+    if (!wo_libm_log) return;
+    if (wo_libm_n < wo_libm_cap) { float* q = wo_libm_log + 4 * (size_t)wo_libm_n; q[0] = tag; q[1] = a; q[2] = b; q[3] = r; }
+    wo_libm_n++;
+}
+/* the value this build uses for libm call (tag, a, b): glibc's, or the override table's entry for exactly these input bits */
+static inline float wo_libm_call(float tag, float a, float b, float glibc) {
+    float r = glibc;
+    for (uint32_t k = 0; k < wo_libm_ovr_n; k++) {
+        const float* q = wo_libm_ovr + 4 * (size_t)k;
+        if (q[0] == tag && !memcmp(&q[1], &a, 4) && !memcmp(&q[2], &b, 4)) { r = q[3]; break; }
+    }
+    wo_libm_row(tag, a, b, r);
+    return r;
+}
 static float wo_through = TRANSPARENT_THROUGH;
 void wo_set_transparent_through(float t) { wo_through = t; }
 #define DEFAULT_N 1.0f                 /* raytracing.cl:7 */
@@ -424,11 +449,18 @@ static uint32_t trace_pixel(uint32_t id, ray_t primary, const wo_scene* sc, int 
                 v3 shadow_dir = normalize(sub(lo, ip));
                 for (int j = 0; j < SOFT_SHADOWS; j++) {
                     /* fp64 multiplies rounded to fp32 (M_PI is a double constant) */
-                    float theta = (float)(2 * M_PI * (double)xorshift32(&rand_state));
-                    float phi = (float)(M_PI * (double)xorshift32(&rand_state));
-                    float x = L[i].radius * sinf(phi) * cosf(theta);
-                    float y = L[i].radius * sinf(phi) * sinf(theta);
-                    float z = L[i].radius * cosf(phi);
+                    const float u1 = xorshift32(&rand_state), u2 = xorshift32(&rand_state);
+                    float theta = (float)(2 * M_PI * (double)u1);
+                    float phi = (float)(M_PI * (double)u2);
+                    float sp_ = sinf(phi), cp_ = cosf(phi), st_ = sinf(theta), ct_ = cosf(theta);
+                    if (wo_libm_log || wo_libm_ovr) {
+                        wo_libm_row(0.0f, u1, u2, 0.0f);
+                        sp_ = wo_libm_call(1.0f, phi, 0.0f, sp_); cp_ = wo_libm_call(2.0f, phi, 0.0f, cp_);
+                        st_ = wo_libm_call(3.0f, theta, 0.0f, st_); ct_ = wo_libm_call(4.0f, theta, 0.0f, ct_);
+                    }
+                    float x = L[i].radius * sp_ * ct_;
+                    float y = L[i].radius * sp_ * st_;
+                    float z = L[i].radius * cp_;
                     v3 sample = add(lo, V(x, y, z));
                     soft += shadow_path(sample, ip, sc, cnt);
                 }
@@ -440,6 +472,7 @@ static uint32_t trace_pixel(uint32_t id, ray_t primary, const wo_scene* sc, int 
                 v3 h = normalize(add(v, shadow_dir));
                 /* spec/diffuse do not multiply by the material colour (:129-135) */
                 float spec_f = powf(fmaxf_like(0.0f, dot(nrm, h)), (float)m.shininess);
+                if (wo_libm_log || wo_libm_ovr) spec_f = wo_libm_call(5.0f, fmaxf_like(0.0f, dot(nrm, h)), (float)m.shininess, spec_f);
                 top->rgb = add(top->rgb, muls(muls(light_rgb, f_stack[sp - 1] * m.specular), spec_f));
                 float diff_f = fmaxf_like(0.0f, dot(nrm, shadow_dir));
                 top->rgb = add(top->rgb, muls(muls(light_rgb, f_stack[sp - 1] * m.diffuse), diff_f));
@@ -542,6 +575,24 @@ static int render_impl(const wo_camera* cam, const float* rays16, const wo_scene
     (void)threads;
     if (counters) *counters = total;
     return 0;
+}
+
+/* glibc's own results for the three libm functions of the path (tests/golden/libm_divergence.json pins where ocml differs) */
+float wo_libm_sinf(float x) { return sinf(x); }
+float wo_libm_cosf(float x) { return cosf(x); }
+float wo_libm_powf(float x, float y) { return powf(x, y); }
+/* the sample angles of raytracing.cl:99-100: fl32(2 pi u) / fl32(pi u), the products taken in fp64 */
+float wo_libm_angle(float u, int full) { return (float)((full ? 2 * M_PI : M_PI) * (double)u); }
+
+/* one pixel with its libm calls logged (rows of 4 floats, see wo_libm_row): returns the number of rows the pixel produced (<= cap stored) */
+int wo_trace_libm(const wo_camera* cam, const wo_scene* sc, int depth, uint64_t id, uint32_t* out, float* log, uint32_t cap,
+                  const float* overrides, uint32_t n_overrides) {
+    if (depth < 1 || depth > WO_MAX_DEPTH) return -1;
+    wo_libm_log = log; wo_libm_cap = cap; wo_libm_n = 0;
+    wo_libm_ovr = overrides; wo_libm_ovr_n = overrides ? n_overrides : 0;
+    *out = trace_pixel((uint32_t)id, raygen_one(cam, id), sc, depth, NULL, NULL);
+    wo_libm_log = 0; wo_libm_ovr = 0; wo_libm_ovr_n = 0;
+    return (int)wo_libm_n;
 }
 
 int wo_render(const wo_camera* cam, const wo_scene* sc, int depth, uint64_t id_begin,

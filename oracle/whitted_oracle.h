@@ -92,6 +92,10 @@ float wo_shadow(const float to[3], const float from[3], const wo_scene* sc);
 int   wo_find_light(const float o[3], const float d[3], const wo_scene* sc, float color[3]);
 int   wo_find_solid(const float o[3], const float d[3], const wo_scene* sc, float point[3],
                     float normal[3], void* material64);
+/* one pixel with its sinf / cosf / powf calls logged as rows {tag, a, b, result} and, optionally, their results taken from an
+ * override table of the same rows (see whitted_oracle.c); returns the row count */
+int   wo_trace_libm(const wo_camera* cam, const wo_scene* sc, int depth, uint64_t id, uint32_t* out, float* log, uint32_t cap,
+                    const float* overrides, uint32_t n_overrides);
 int   wo_num_threads(void);
 /* factor a transparent sphere applies to a shadow ray (default 0.8f = primitives.cl:7); see whitted_oracle.c */
 void  wo_set_transparent_through(float t);
