@@ -35,7 +35,7 @@ SYMBOLS = [
     "clw_ext_timing_reset", "clw_ext_timing_get", "clw_ext_set_timing_every", "clw_ext_set_pipeline", "clw_ext_load_images_raw",
     "clw_ext_bind_device_buffer", "clw_ext_device_ptr", "clw_ext_set_debug_rgb",
     "clw_ext_enable_counters", "clw_ext_read_counters", "clw_ext_set_tile_sched", "clw_ext_read_tile_costs", "clw_ext_unit", "clw_ext_set_grid", "clw_ext_set_variant",
-    "clw_ext_set_shadow_through", "clw_ext_invalidate_scene", "clw_ext_read_counters_ex", "clw_ext_unit_scene",
+    "clw_ext_set_shadow_through", "clw_ext_set_tpt", "clw_ext_invalidate_scene", "clw_ext_read_counters_ex", "clw_ext_unit_scene",
     "clw_host_perspective", "clw_host_write_png", "clw_host_write_png_rgba", "clw_host_read_png",
     "clw_host_free", "clw_ext_version",
 ]
@@ -92,6 +92,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                  "clw_ext_set_variant", "clw_ext_set_tile_sched", "clw_ext_set_grid"):
         getattr(L, name).argtypes = [W, C.c_int]
     L.clw_ext_set_shadow_through.argtypes = [W, C.c_float]
+    if hasattr(L, "clw_ext_set_tpt") or not os.environ.get("CLWRAP_LIB"):      # (an older A/B build may lack it)
+        L.clw_ext_set_tpt.argtypes = [W, C.c_int, C.c_int, C.c_int]
     L.clw_ext_set_id_offset.argtypes = [W, C.c_uint64]
     L.clw_ext_set_row_bands.argtypes = [W, u32, u32]
     L.clw_ext_sync.argtypes = [W]
@@ -252,6 +254,7 @@ class ClWrap:
     def set_grid(self, on): self.L.clw_ext_set_grid(C.byref(self.w), int(on))
     def set_tile_sched(self, on): self.L.clw_ext_set_tile_sched(C.byref(self.w), int(on))
     def set_variant(self, v): self.L.clw_ext_set_variant(C.byref(self.w), int(v))
+    def set_tpt(self, max_lanes=-1, min_paths=-1, pool_mb=-1): self.L.clw_ext_set_tpt(C.byref(self.w), int(max_lanes), int(min_paths), int(pool_mb))
     def timing_reset(self): self.L.clw_ext_timing_reset(C.byref(self.w))
     def set_timing_every(self, n): self.L.clw_ext_set_timing_every(C.byref(self.w), int(n))
     def set_pipeline(self, on): self.L.clw_ext_set_pipeline(C.byref(self.w), int(on))
@@ -284,6 +287,7 @@ class ClWrap:
                  "lane_iters", "wave_iters_x64", "shadow_rays_traced", "lights_classified"]
         d = dict(zip(names, [int(x) for x in out]))
         d["vis_mismatches"] = int(out[28])
+        d["tpt_gave_up"], d["tpt_tiles"], d["tpt_nodes"] = int(out[29]), int(out[30]), int(out[31])   # tree-parallel tail (deep launches)
         return d
 
     def invalidate_scene(self): self.L.clw_ext_invalidate_scene(C.byref(self.w))

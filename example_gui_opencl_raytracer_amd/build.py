@@ -21,7 +21,8 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CC = os.environ.get("CC") or "gcc"
 
-DEVICE_DEPS = ["whitted_trace.inc", "whitted_hit.inc", "whitted_bounce.inc", "whitted_pop.inc", "whitted_launch.inc", "whitted_params.h"]
+DEVICE_DEPS = ["whitted_trace.inc", "whitted_hit.inc", "whitted_shade.inc", "whitted_bounce.inc", "whitted_pop.inc", "whitted_tpt.inc", "whitted_terms.inc",
+               "whitted_launch.inc", "whitted_params.h"]
 UNITS = [
     # (source, compiler, flags, extra deps)
     # -ffp-contract=off on BOTH builds: the fast build fuses where its source says fma, nowhere else.

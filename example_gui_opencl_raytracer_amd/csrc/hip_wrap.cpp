@@ -13,6 +13,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -35,7 +36,7 @@ extern "C" hipError_t wt_fast_launch_unit(int, const float*, float*, unsigned, u
 extern "C" hipError_t wt_strict_launch_unit(int, const float*, float*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 extern "C" hipError_t wt_fast_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
 extern "C" hipError_t wt_strict_launch_unit_scene(const whitted_params*, int, int, const float*, float*, unsigned, unsigned, unsigned, size_t, hipStream_t);
-extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, unsigned, hipStream_t);
+extern "C" hipError_t wt_fast_launch_sched(const unsigned*, unsigned*, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t);
 
 namespace {
 
@@ -44,6 +45,15 @@ enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC =
  * the deepest refraction trees grows with the depth, the throughput part with the tile count (tools/occ_sweep.py on
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
 constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
+/* tree-parallel tail (whitted_tpt.inc): a deep launch enters it with at most TPT_MAX_LANES live lanes holding at least TPT_MIN_PATHS
+ * pending paths; a workgroup's slice is at most TPT_SLICE_WORDS_MAX words and the whole pool at most TPT_POOL_MB (a launch with more
+ * workgroups gets smaller slices; below TPT_MIN_CAP nodes per slice it runs without the tail) */
+constexpr unsigned TPT_MAX_LANES = 24, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160;
+constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
+/* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
+ * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its
+ * fixed costs); the quota is the share's total cost over the wavefronts its CUs hold at a time */
+constexpr unsigned SPLIT_EXTRA_PER_SHARE = 1024, SPLIT_MIN_QUOTA = 3000, SPLIT_SLOTS = 384, SPLIT_SLOTS_OCC = 640;
 constexpr size_t COUNTER_WORDS = CLW_NUM_COUNTERS + 16 * (size_t)CLW_STAMP_SHARDS;
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
@@ -160,7 +170,7 @@ struct Impl {
         bool have[2] = {false, false};                /* order[i] holds / will hold a schedule */
         int wr = 0;                                   /* cost buffer the next trace writes */
         hipEvent_t traced = nullptr;
-        uint32_t w = 0, rows = 0;
+        uint32_t w = 0, rows = 0, cap = 0;           /* frame the buffers were sized for; dispatch entries per XCD share */
         RaygenArgs sig{}; int sig_depth = 0; uint64_t sig_scene = 0; bool sig_valid = false; int sig_age = 0, newest = 0; uint64_t frame = 0, newest_frame = 0;   /* what the newest order was built for, frames since */
         void reset() { have[0] = have[1] = false; sig_valid = false; newest = 0; }
         void free_all() {
@@ -185,6 +195,10 @@ struct Impl {
     /* timing log */
     std::vector<TimingEntry> timing;
     unsigned occ_tiles_per_depth = OCC_TILES_PER_DEPTH;   /* CLWRAP_OCC_TILES_PER_DEPTH: tuning knob */
+    /* the tree-parallel tail of deep launches (whitted_tpt.inc): one slice of node storage per workgroup of the launch */
+    uint32_t* d_tpt_pool = nullptr; size_t tpt_pool_bytes = 0;
+    unsigned tpt_max = TPT_MAX_LANES, tpt_min = TPT_MIN_PATHS, tpt_pool_mb = TPT_POOL_MB;   /* CLWRAP_TPT_MAX / _MIN / _POOL_MB, clw_ext_set_tpt */
+    unsigned split_min_quota = SPLIT_MIN_QUOTA;           /* CLWRAP_SPLIT_MIN_QUOTA; 0 = heavy tiles are not split */
     bool timing_on = false;                       /* switched on by the first clw_ext_timing_reset / set_timing_every */
     uint32_t timing_every = 1, timing_tick = 0;   /* events around every n-th launch only */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -474,7 +488,6 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     P.depth = I->depth;
     P.out = (uint32_t*)out->dptr;
     P.out_rgb = I->debug_rgb;
-    P.coop_max = (I->variant & 16) ? 0u : 10u;
     P.diag = (I->variant & 512) ? (env_int("CLWRAP_TIMELINE_EDGES", 0) ? 255u + (uint32_t)env_int("CLWRAP_TIMELINE_EDGES", 0) : 1u + (uint32_t)env_int("CLWRAP_TIMELINE_SHIFT", 0)) : 0u;
 
     const bool fused = I->fuse && rays->gen_valid && !rays->exposed;   /* (a buffer whose pointer was handed out is read, not regenerated) */
@@ -525,13 +538,20 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     unsigned grid;
     Impl::Sched& S = I->scheds[strip ? strip->slot : 0];
     bool sched_rebuild = false;
-    unsigned trows = 0, tpr = 0, per_share = 0;
+    unsigned trows = 0, tpr = 0, per_share = 0, per_share_cap = 0, base_grid = 0;
+    /* deep launches with the tree-parallel tail: a tile's cost is its total work, and heavy tiles are split over several wavefronts */
+    const bool tail_wanted = (flags & F_DEEP) && !(I->variant & 16) && I->tpt_max != 0u;
+    bool split = false;
     if (P.tiled) {
         trows = (P.rows + 7) / 8; tpr = (P.width + 7) / 8;
         per_share = ((trows + 7) / 8) * tpr;
-        grid = 8 * per_share;
-        if (I->sched && !(I->variant & 4) && trows <= 0xFFFEu && tpr <= 0xFFFFu) {   /* the order packs (tile row << 16 | column) */
-            if (S.w != P.width || S.rows != P.rows || !S.cost[0]) {
+        per_share_cap = per_share;
+        grid = base_grid = 8 * per_share;
+        if (I->sched && !(I->variant & 4) && trows <= 0xFFFu && tpr <= 0xFFFu) {   /* the order packs (tile column | row << 12 | parts) */
+            split = tail_wanted && !(flags & F_GRID) && I->split_min_quota != 0u && !(I->variant & 4096);
+            if (split) { per_share_cap = per_share + SPLIT_EXTRA_PER_SHARE; grid = 8 * per_share_cap; }
+            P.cost_sum = (tail_wanted && !(flags & F_GRID)) ? 1u : 0u;
+            if (S.w != P.width || S.rows != P.rows || S.cap != per_share_cap || !S.cost[0]) {
                 S.free_all();
                 for (int i = 0; i < 2; i++) {
                     HIP_OK(hipMalloc((void**)&S.cost[i], (size_t)trows * tpr * 4), "Couldn't allocate device memory");
@@ -539,7 +559,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
                     HIP_OK(hipEventCreateWithFlags(&S.built[i], hipEventDisableTiming), "Couldn't create a timing event");
                 }
                 HIP_OK(hipEventCreateWithFlags(&S.traced, hipEventDisableTiming), "Couldn't create a timing event");
-                S.w = P.width; S.rows = P.rows; S.wr = 0;
+                S.w = P.width; S.rows = P.rows; S.cap = per_share_cap; S.wr = 0;
             }
             const int wr = S.wr;
             P.tile_cost = S.cost[wr];
@@ -554,6 +574,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             P.tile_order = rd >= 0 ? S.order[rd] : nullptr;
             /* the costs can only change when the camera, the depth or the scene did */
             sched_rebuild = !S.sig_valid || !same_raygen(g, S.sig) || S.sig_depth != I->depth || S.sig_scene != I->scene_generation;
+            /* (costs that add up: the buffer starts at zero; the build that read it two frames ago has been waited for above) */
+            if (P.cost_sum) HIP_OK(hipMemsetAsync(S.cost[wr], 0, (size_t)trows * tpr * 4, I->stream), "Couldn't run the kernel");
             if (sched_rebuild) { S.sig = g; S.sig_depth = I->depth; S.sig_scene = I->scene_generation; S.sig_valid = true; S.sig_age = 0; }
             /* Grid builds measure a tile by its wave's lifetime, which depends on the company it ran in: the order built
              * from the first (unsorted, often cold) frame is refined once from the first sorted one. */
@@ -563,9 +585,32 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     } else {
         grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
-    if ((flags & F_DEEP) && !I->strict && (uint64_t)grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
+    if ((flags & F_DEEP) && !I->strict && (uint64_t)(P.tiled ? base_grid : grid) >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
     /* deep launches: the scratch part of the DFS stack is sized for the launch's depth (7 / 15 / 31 parents) */
     if ((flags & F_DEEP) && !(flags & F_COUNT) && !(I->variant & 2048)) flags |= I->depth <= 8 ? F_D8 : (I->depth <= 16 ? F_D16 : 0);
+    if (tail_wanted) {
+        /* node storage of the tree-parallel tail: (23 + weights per light x lights) words per node, the parked lane state and the
+         * replay's saved sums (whitted_tpt.inc) */
+        const uint64_t per_node = 23u + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
+        const uint64_t fixed = 25u * 64u + (uint64_t)I->depth * 3u * 64u;
+        uint64_t slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / grid) & ~(uint64_t)63;
+        uint64_t cap = slice > fixed ? (slice - fixed) / per_node : 0;
+        if (cap > 65000u) { cap = 65000u; slice = (cap * per_node + fixed + 63u) & ~(uint64_t)63; }   /* node ids are 16 bits */
+        if (cap >= TPT_MIN_CAP) {
+            const size_t need = (size_t)slice * 4u * grid;
+            if (I->tpt_pool_bytes < need) {
+                finish(I);
+                if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
+                I->d_tpt_pool = nullptr; I->tpt_pool_bytes = 0;
+                if (hipMalloc((void**)&I->d_tpt_pool, need) == hipSuccess) I->tpt_pool_bytes = need;
+                else (void)hipGetLastError();          /* no room: the launch runs without the tail */
+            }
+            if (I->d_tpt_pool) {
+                P.tpt_pool = I->d_tpt_pool; P.tpt_slice_words = (uint32_t)slice; P.tpt_cap = (uint32_t)cap;
+                P.tpt_max = std::min(I->tpt_max, 64u); P.tpt_min = I->tpt_min;
+            }
+        }
+    }
     LaunchTimer t(I, kid);
     hipError_t e = I->strict ? wt_strict_launch_trace(&P, flags, grid, dyn_lds, I->stream)
                              : wt_fast_launch_trace(&P, flags, grid, dyn_lds, I->stream);
@@ -577,7 +622,8 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             if (!I->sched_stream) HIP_OK(hipStreamCreateWithFlags(&I->sched_stream, hipStreamNonBlocking), "Couldn't create a command queue for the given device");
             HIP_OK(hipEventRecord(S.traced, I->stream), "Couldn't run the kernel");
             HIP_OK(hipStreamWaitEvent(I->sched_stream, S.traced, 0), "Couldn't run the kernel");
-            if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, (flags & F_GRID) ? 1u : 0u, I->sched_stream) != hipSuccess)
+            if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, (flags & F_GRID) ? 1u : 0u, per_share_cap,
+                                     split ? ((flags & F_OCC) ? SPLIT_SLOTS_OCC : SPLIT_SLOTS) : 0u, I->split_min_quota, I->sched_stream) != hipSuccess)
                 die("Couldn't run the kernel");
             HIP_OK(hipEventRecord(S.built[wr], I->sched_stream), "Couldn't run the kernel");
             S.have[wr] = true; S.newest = wr; S.newest_frame = S.frame - 1;
@@ -701,6 +747,10 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->stamps = env_int("CLWRAP_STAMPS", 0) ? 1 : 0;
     if (const char* th = getenv("CLWRAP_THROUGH")) { if (*th) I->through = (float)atof(th); }
     I->occ_tiles_per_depth = (unsigned)env_int("CLWRAP_OCC_TILES_PER_DEPTH", (int)OCC_TILES_PER_DEPTH);
+    I->tpt_max = (unsigned)env_int("CLWRAP_TPT_MAX", (int)TPT_MAX_LANES);
+    I->tpt_min = (unsigned)env_int("CLWRAP_TPT_MIN", (int)TPT_MIN_PATHS);
+    I->tpt_pool_mb = (unsigned)env_int("CLWRAP_TPT_POOL_MB", (int)TPT_POOL_MB);
+    I->split_min_quota = (unsigned)env_int("CLWRAP_SPLIT_MIN_QUOTA", (int)SPLIT_MIN_QUOTA);
 
     wrap->impl = I;
     wrap->kernels_num = (cl_uint)I->kernels.size();
@@ -821,6 +871,7 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_geom) (void)hipFree(I->d_geom);
     if (I->d_ptex) (void)hipFree(I->d_ptex);
     if (I->d_counters) (void)hipFree(I->d_counters);
+    if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
     for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
     if (I->d_grid_geom) (void)hipFree(I->d_grid_geom);
     if (I->sched_stream) (void)hipStreamSynchronize(I->sched_stream);
@@ -912,6 +963,12 @@ void clw_ext_set_shadow_through(cl_wrap* wrap, float factor) { impl_of(wrap)->th
 void clw_ext_set_grid(cl_wrap* wrap, int on) { impl_of(wrap)->use_grid = on ? 1 : 0; }
 void clw_ext_set_tile_sched(cl_wrap* wrap, int on) { Impl* I = impl_of(wrap); I->sched = on ? 1 : 0; for (auto& sc : I->scheds) sc.reset(); }
 void clw_ext_set_variant(cl_wrap* wrap, int variant) { impl_of(wrap)->variant = variant; }
+void clw_ext_set_tpt(cl_wrap* wrap, int max_lanes, int min_paths, int pool_mb) {
+    Impl* I = impl_of(wrap);
+    if (max_lanes >= 0) I->tpt_max = (unsigned)std::min(max_lanes, 64);
+    if (min_paths >= 0) I->tpt_min = (unsigned)min_paths;
+    if (pool_mb >= 0) I->tpt_pool_mb = (unsigned)pool_mb;
+}
 void clw_ext_set_debug_rgb(cl_wrap* wrap, void* p) { impl_of(wrap)->debug_rgb = (float*)p; }
 
 void clw_ext_set_pipeline(cl_wrap* wrap, int on) { impl_of(wrap)->pipeline = on ? 1 : 0; }

@@ -39,11 +39,17 @@ typedef struct {
      * ((y/8)*band_stride + band_phase)*8 + y%8; band_stride <= 1 = contiguous range        */
     uint32_t band_stride, band_phase;
     /* cost-sorted tile dispatch (tiled mode; both nullable): tile_order[b] = tile served by workgroup b
-     * (packed: tile row << 16 | tile column; 0xFFFFFFFF = none), heaviest tiles of the previous frame first, one list per
+     * (packed: tile column | tile row << 12 | log2(parts) << 24 | part << 27; 0xFFFFFFFF = none), heaviest tiles of the previous frame first, one list per
      * XCD interleaved as order[8*j + k]; tile_cost[tile] receives this frame's cost of every tile.  */
     const uint32_t* tile_order;
     uint32_t* tile_cost;
-    uint32_t coop_max;     /* <= this many shading lanes -> their shadow rays are spread over the wave (0 = never) */
+    /* the tree-parallel tail of deep launches (whitted_tpt.inc): once at most tpt_max lanes of a tile's wave are alive and they hold at
+     * least tpt_min pending paths, the rest of the tile is traced by the whole wave as one pool of segments whose nodes live in the
+     * tile's slice of tpt_pool: workgroup b owns words [b * tpt_slice_words, (b + 1) * tpt_slice_words), room for tpt_cap nodes
+     * (0 = no tail: the per-lane loop runs to the end) */
+    uint32_t* tpt_pool;
+    uint32_t tpt_slice_words, tpt_cap, tpt_max, tpt_min;
+    uint32_t cost_sum;     /* 1: a tile's cost is the SUM over its lanes (and over the wavefronts that share the tile), added atomically to a zeroed tile_cost; 0: the maximum over its lanes, stored */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */
     const float* geom;     /* float4 stream, layout above                             */

@@ -156,14 +156,24 @@ void clw_ext_unit_scene(cl_wrap* wrap, cl_uint kernel_id, int op, const float* i
 
 /* Kernel build variant for A/B measurements and equivalence tests (same image in every variant); 0 = default.  Bits:
  * 1 geometry from global memory instead of LDS, 2 linear work-item ids instead of 8x8 tiles, 4 no cost-sorted tile
- * order, 8 no uniform grid, 16 no cooperative sparse-tail loop, 64 never the high-occupancy flavour of the deep build,
+ * order, 8 no uniform grid, 16 no tree-parallel tail (deep launches run their per-lane loop to the end), 64 never the high-occupancy flavour of the deep build,
  * 128 no light / plane side table (every shadow ray tests every plane), 256 no visibility classes (every needed shadow ray is traced),
+ * 4096 heavy tiles of deep launches are not split over several wavefronts,
  * 2048 deep launches always carry the full-depth (31-parent) scratch stack instead of one sized for their depth,
  * 1024 (with clw_ext_enable_counters) VERIFICATION of the visibility classes: lights are classified AND traced, counter word 9 =
  * lights classified, word 28 = lights whose traced factors differ from their class's (must read 0),
  * 512 DIAGNOSTIC builds only (-DWT_TIMELINE=1, tools/timeline.py): the tile-cost buffer receives when each tile's wave ran inside the launch
  * (CLWRAP_TIMELINE_SHIFT = tick of 10 ns << shift; CLWRAP_TIMELINE_EDGES = 1 / 2: its prologue and epilogue instead); no effect otherwise. */
 void clw_ext_set_variant(cl_wrap* wrap, int variant);
+
+/* The tree-parallel tail of deep launches (depth > 4; csrc/whitted_tpt.inc): once at most `max_lanes` lanes of a tile's wavefront are
+ * alive and they hold at least `min_paths` pending paths (current segments + continuations on their stacks), the rest of the tile is
+ * traced by the whole wavefront as one pool of segments kept in a per-workgroup slice of a device pool of at most `pool_mb` MiB.
+ * Same image whatever the settings (the per-lane loop and the tail do the same arithmetic and add in the same order); max_lanes 64 sends
+ * everything through the tail, 0 switches it off; a negative argument keeps the current value.  Defaults 24 / 4 / 8192, or
+ * CLWRAP_TPT_MAX / CLWRAP_TPT_MIN / CLWRAP_TPT_POOL_MB.  Counting build: counter words 29 / 30 / 31 = tiles the tail gave up on (slice
+ * full: finished by the per-lane loop) / tiles it finished / nodes it traced. */
+void clw_ext_set_tpt(cl_wrap* wrap, int max_lanes, int min_paths, int pool_mb);
 
 /* Host helper: camera -> the eight by-value raygen arguments, with the reference's exact
  * mixed float/double arithmetic (rinit_camera + rgen_perspective, src/cpu_ray.c:8-35, 42-106).

@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 400 python tools/tpt_check.py quick > gpurun_out/tpt_quick.log 2>&1
+rc=$?; echo "rc=$rc"; grep -c "pixels ==" gpurun_out/tpt_quick.log; grep "!=" gpurun_out/tpt_quick.log | cut -c1-260; tail -1 gpurun_out/tpt_quick.log
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 600 python tools/tpt_check.py time ref800,c3s,hd15 0,4,8,16,24,32,48,64 > gpurun_out/tpt_time.log 2>&1
+echo "time rc=$?"; cat gpurun_out/tpt_time.log | cut -c1-250
+for cfg in ref800 c3; do
+  bash tools/ab_cfg.sh $cfg --variant 16 -- "" _old 2>&1 | tee -a gpurun_out/tpt_ab.log
+done

@@ -24,6 +24,7 @@ else:
     cam = dict(origin=(0.0, 12.0, -10.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
 r = Renderer(sc, textures.texture_layers(), textures.skybox_cross(4096), W, H, depth=depth, strict=strict)
 r.look(**cam)
+if "--tpt" in sys.argv: r.w.set_tpt(int(sys.argv[sys.argv.index("--tpt") + 1]), -1, -1)
 for _ in range(6):
     r.render(readback=False)
 r.w.sync()
@@ -51,6 +52,7 @@ busy = [int(((s <= x) & (e > x)).sum()) for x in (edges[:-1] + edges[1:]) / 2]
 dur = e - s
 print(json.dumps(dict(config=cfg, strict=strict, kernel_ms=round(ms / n, 4), span_us=round(span * tick_us, 2), tiles=int(c.size),
                       mean_wave_us=round(float(dur.mean()) * tick_us, 2), max_wave_us=round(float(dur.max()) * tick_us, 2),
+                      longest_us=[round(float(x) * tick_us, 1) for x in np.sort(dur)[-8:][::-1]], waves_over_50us=int((dur * tick_us > 50).sum()),
                       last_start_us=round(float(s.max()) * tick_us, 2), busy_waves_per_5pct=busy,
                       mean_busy=round(float(dur.sum()) / max(span, 1), 1))))
 r.release()
