@@ -46,9 +46,9 @@ enum { F_COUNT = 1, F_DEEP = 2, F_GEOM_LDS = 4, F_RAYS = 8, F_GRID = 16, F_OCC =
  * render.map: wins 12-14 % at 2560x1440 depth 6 and 3840x2160 depth 6-8, loses 2-5 % at 1920x1080 and at depth 15) */
 constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
 /* tree-parallel tail (whitted_tpt.inc): a deep launch enters it with at most TPT_MAX_LANES live lanes holding at least TPT_MIN_PATHS
- * pending paths; a workgroup's slice is at most TPT_SLICE_WORDS_MAX words and the whole pool at most TPT_POOL_MB (a launch with more
- * workgroups gets smaller slices; below TPT_MIN_CAP nodes per slice it runs without the tail) */
-constexpr unsigned TPT_MAX_LANES = 24, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160;
+ * pending paths; the pool holds TPT_SLOTS_PER_XCC slots per XCD (more than an XCD's CUs hold wavefronts) of at most TPT_SLICE_WORDS_MAX
+ * words, TPT_POOL_MB in all (below TPT_MIN_CAP nodes per slot -- hundreds of lights -- the launch runs without the tail) */
+constexpr unsigned TPT_MAX_LANES = 24, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160, TPT_SLOTS_PER_XCC = 1024;
 constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
 /* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
  * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its
@@ -196,7 +196,7 @@ struct Impl {
     std::vector<TimingEntry> timing;
     unsigned occ_tiles_per_depth = OCC_TILES_PER_DEPTH;   /* CLWRAP_OCC_TILES_PER_DEPTH: tuning knob */
     /* the tree-parallel tail of deep launches (whitted_tpt.inc): one slice of node storage per workgroup of the launch */
-    uint32_t* d_tpt_pool = nullptr; size_t tpt_pool_bytes = 0;
+    uint32_t* d_tpt_pool = nullptr; uint32_t* d_tpt_flags = nullptr; size_t tpt_pool_bytes = 0;
     unsigned tpt_max = TPT_MAX_LANES, tpt_min = TPT_MIN_PATHS, tpt_pool_mb = TPT_POOL_MB;   /* CLWRAP_TPT_MAX / _MIN / _POOL_MB, clw_ext_set_tpt */
     unsigned split_min_quota = SPLIT_MIN_QUOTA;           /* CLWRAP_SPLIT_MIN_QUOTA; 0 = heavy tiles are not split */
     bool timing_on = false;                       /* switched on by the first clw_ext_timing_reset / set_timing_every */
@@ -589,24 +589,33 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     /* deep launches: the scratch part of the DFS stack is sized for the launch's depth (7 / 15 / 31 parents) */
     if ((flags & F_DEEP) && !(flags & F_COUNT) && !(I->variant & 2048)) flags |= I->depth <= 8 ? F_D8 : (I->depth <= 16 ? F_D16 : 0);
     if (tail_wanted) {
-        /* node storage of the tree-parallel tail: (23 + weights per light x lights) words per node, the parked lane state and the
-         * replay's saved sums (whitted_tpt.inc) */
-        const uint64_t per_node = 23u + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
+        /* node storage of the tree-parallel tail: (27 or 29 + weights per light x lights) words per node, the parked lane state and the
+         * replay's saved sums (whitted_tpt.inc); TPT_SLOTS_PER_XCC slots per XCD, taken and handed back by the waves themselves */
+        const uint64_t per_node = (I->strict ? 29u : 27u) + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
         const uint64_t fixed = 25u * 64u + (uint64_t)I->depth * 3u * 64u;
-        uint64_t slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / grid) & ~(uint64_t)63;
-        uint64_t cap = slice > fixed ? (slice - fixed) / per_node : 0;
-        if (cap > 65000u) { cap = 65000u; slice = (cap * per_node + fixed + 63u) & ~(uint64_t)63; }   /* node ids are 16 bits */
+        const uint64_t nslots = 8u * (uint64_t)TPT_SLOTS_PER_XCC;
+        uint64_t slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / nslots) & ~(uint64_t)63;
+        uint64_t cap = slice > fixed ? ((slice - fixed) / per_node) & ~(uint64_t)63 : 0;   /* whole blocks of 64 nodes */
+        if (cap > 64960u) cap = 64960u;                /* node ids are 16 bits */
         if (cap >= TPT_MIN_CAP) {
-            const size_t need = (size_t)slice * 4u * grid;
-            if (I->tpt_pool_bytes < need) {
+            const size_t need = (size_t)slice * 4u * nslots;
+            if (I->tpt_pool_bytes != need) {
                 finish(I);
                 if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
-                I->d_tpt_pool = nullptr; I->tpt_pool_bytes = 0;
-                if (hipMalloc((void**)&I->d_tpt_pool, need) == hipSuccess) I->tpt_pool_bytes = need;
-                else (void)hipGetLastError();          /* no room: the launch runs without the tail */
+                if (I->d_tpt_flags) (void)hipFree(I->d_tpt_flags);
+                I->d_tpt_pool = nullptr; I->d_tpt_flags = nullptr; I->tpt_pool_bytes = 0;
+                if (hipMalloc((void**)&I->d_tpt_pool, need) == hipSuccess && hipMalloc((void**)&I->d_tpt_flags, nslots * 4u) == hipSuccess) {
+                    HIP_OK(hipMemset(I->d_tpt_flags, 0, nslots * 4u), "Couldn't allocate device memory");
+                    I->tpt_pool_bytes = need;
+                } else {                                /* no room: the launch runs without the tail */
+                    (void)hipGetLastError();
+                    if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
+                    I->d_tpt_pool = nullptr;
+                }
             }
-            if (I->d_tpt_pool) {
-                P.tpt_pool = I->d_tpt_pool; P.tpt_slice_words = (uint32_t)slice; P.tpt_cap = (uint32_t)cap;
+            if (I->tpt_pool_bytes) {
+                P.tpt_pool = I->d_tpt_pool; P.tpt_flags = I->d_tpt_flags; P.tpt_slice_words = (uint32_t)slice; P.tpt_cap = (uint32_t)cap;
+                P.tpt_slots = TPT_SLOTS_PER_XCC;
                 P.tpt_max = std::min(I->tpt_max, 64u); P.tpt_min = I->tpt_min;
             }
         }
@@ -872,6 +881,7 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_ptex) (void)hipFree(I->d_ptex);
     if (I->d_counters) (void)hipFree(I->d_counters);
     if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
+    if (I->d_tpt_flags) (void)hipFree(I->d_tpt_flags);
     for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
     if (I->d_grid_geom) (void)hipFree(I->d_grid_geom);
     if (I->sched_stream) (void)hipStreamSynchronize(I->sched_stream);

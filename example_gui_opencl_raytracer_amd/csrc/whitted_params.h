@@ -44,11 +44,12 @@ typedef struct {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     /* the tree-parallel tail of deep launches (whitted_tpt.inc): once at most tpt_max lanes of a tile's wave are alive and they hold at
-     * least tpt_min pending paths, the rest of the tile is traced by the whole wave as one pool of segments whose nodes live in the
-     * tile's slice of tpt_pool: workgroup b owns words [b * tpt_slice_words, (b + 1) * tpt_slice_words), room for tpt_cap nodes
-     * (0 = no tail: the per-lane loop runs to the end) */
+     * least tpt_min pending paths, the rest of the tile is traced by the whole wave as one pool of segments whose nodes live in a slot
+     * of tpt_pool: 8 x tpt_slots slots (tpt_slots per XCD) of tpt_slice_words words, room for tpt_cap nodes each; tpt_flags[8 * tpt_slots]:
+     * 1 = slot taken (tpt_cap 0 = no tail: the per-lane loop runs to the end) */
     uint32_t* tpt_pool;
-    uint32_t tpt_slice_words, tpt_cap, tpt_max, tpt_min;
+    uint32_t* tpt_flags;
+    uint32_t tpt_slice_words, tpt_cap, tpt_slots, tpt_max, tpt_min;
     uint32_t cost_sum;     /* 1: a tile's cost is the SUM over its lanes (and over the wavefronts that share the tile), added atomically to a zeroed tile_cost; 0: the maximum over its lanes, stored */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */

@@ -65,5 +65,5 @@ for cfg in which:
             for _ in range(nfr): r.render(readback=False)
             r.w.sync(); n, ms = r.w.timing_get(1); r.w.set_async(0)
             print(json.dumps(dict(config=cfg, strict=strict, tpt_max=tpt, kernel_ms=round(ms / n, 4), same=bool(np.array_equal(img, ref)), tail_tiles=c["tpt_tiles"],
-                                  gave_up=c["tpt_gave_up"], nodes=c["tpt_nodes"], lane_util=round(c["lane_iters"] / max(c["wave_iters_x64"], 1), 4))), flush=True)
+                                  gave_up=c["tpt_gave_up"], nodes=c["tpt_nodes"], phase_us=c["tpt_phase_us"], batches=c["tpt_batches"], max_batches=c["tpt_max_batches"], max_nodes=c["tpt_max_nodes"], longest_us=c["tpt_longest_us"], lane_util=round(c["lane_iters"] / max(c["wave_iters_x64"], 1), 4))), flush=True)
         r.release()
