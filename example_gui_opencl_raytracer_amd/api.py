@@ -289,6 +289,7 @@ class ClWrap:
         d["vis_mismatches"] = int(out[28])
         d["tpt_gave_up"], d["tpt_tiles"], d["tpt_nodes"] = int(out[29]), int(out[30]), int(out[31])   # tree-parallel tail (deep launches)
         d["tpt_batches"], d["tpt_max_batches"], d["tpt_max_nodes"], d["tpt_longest_us"] = int(out[16]), int(out[17]), int(out[18]), round(int(out[19]) * 0.01, 1)
+        d["tpt_phase_max_us"] = [round(int(out[20 + k]) * 0.01, 1) for k in range(6)]
         d["tpt_phase_us"] = [round(int(out[10 + k]) * 0.01, 1) for k in range(6)]   # roots, expansion, order, RNG, shading, replay (summed over tiles)
         return d
 

@@ -48,7 +48,7 @@ constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
 /* tree-parallel tail (whitted_tpt.inc): a deep launch enters it with at most TPT_MAX_LANES live lanes holding at least TPT_MIN_PATHS
  * pending paths; the pool holds TPT_SLOTS_PER_XCC slots per XCD (more than an XCD's CUs hold wavefronts) of at most TPT_SLICE_WORDS_MAX
  * words, TPT_POOL_MB in all (below TPT_MIN_CAP nodes per slot -- hundreds of lights -- the launch runs without the tail) */
-constexpr unsigned TPT_MAX_LANES = 24, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160, TPT_SLOTS_PER_XCC = 1024;
+constexpr unsigned TPT_MAX_LANES = 48, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160, TPT_SLOTS_PER_XCC = 1024;
 constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
 /* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
  * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its
@@ -198,6 +198,7 @@ struct Impl {
     /* the tree-parallel tail of deep launches (whitted_tpt.inc): one slice of node storage per workgroup of the launch */
     uint32_t* d_tpt_pool = nullptr; uint32_t* d_tpt_flags = nullptr; size_t tpt_pool_bytes = 0;
     unsigned tpt_max = TPT_MAX_LANES, tpt_min = TPT_MIN_PATHS, tpt_pool_mb = TPT_POOL_MB;   /* CLWRAP_TPT_MAX / _MIN / _POOL_MB, clw_ext_set_tpt */
+    int tpt_clock = 0;                                    /* CLWRAP_TPT_CLOCK=1: DIAGNOSTIC phase clock of the tail (counter words 10-25) */
     unsigned split_min_quota = SPLIT_MIN_QUOTA;           /* CLWRAP_SPLIT_MIN_QUOTA; 0 = heavy tiles are not split */
     bool timing_on = false;                       /* switched on by the first clw_ext_timing_reset / set_timing_every */
     uint32_t timing_every = 1, timing_tick = 0;   /* events around every n-th launch only */
@@ -527,8 +528,9 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     }
     if (I->depth > SHALLOW_LEVELS + 1) flags |= F_DEEP;
     if (!(flags & F_GEOM_LDS)) P.vis = 0;
-    if (I->counting || I->stamps) {
+    if (I->counting || I->stamps || I->tpt_clock) {
         if (I->counting) flags |= F_COUNT;
+        P.tpt_clock = I->tpt_clock ? 1u : 0u;
         if (!I->d_counters) {
             HIP_OK(hipMalloc((void**)&I->d_counters, COUNTER_WORDS * sizeof(unsigned long long)), "Couldn't allocate device memory");
             HIP_OK(hipMemsetAsync(I->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), I->stream), "Couldn't allocate device memory");
@@ -540,13 +542,20 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     bool sched_rebuild = false;
     unsigned trows = 0, tpr = 0, per_share = 0, per_share_cap = 0, base_grid = 0;
     /* deep launches with the tree-parallel tail: a tile's cost is its total work, and heavy tiles are split over several wavefronts */
-    const bool tail_wanted = (flags & F_DEEP) && !(I->variant & 16) && I->tpt_max != 0u;
-    bool split = false;
     if (P.tiled) {
         trows = (P.rows + 7) / 8; tpr = (P.width + 7) / 8;
         per_share = ((trows + 7) / 8) * tpr;
         per_share_cap = per_share;
         grid = base_grid = 8 * per_share;
+    } else {
+        grid = base_grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    }
+    /* big deep launches are throughput-bound: the high-occupancy flavour (96 VGPRs, five waves per SIMD) -- which does not carry the tail:
+     * under that register cap the tail's passes spill, and its code cost the per-lane loop 6 % (4096^2 depth 8: 7.4 -> 7.9 ms) */
+    if ((flags & F_DEEP) && !I->strict && (uint64_t)base_grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
+    const bool tail_wanted = (flags & F_DEEP) && !(flags & F_OCC) && !(I->variant & 16) && I->tpt_max != 0u;
+    bool split = false;
+    if (P.tiled) {
         if (I->sched && !(I->variant & 4) && trows <= 0xFFFu && tpr <= 0xFFFu) {   /* the order packs (tile column | row << 12 | parts) */
             split = tail_wanted && !(flags & F_GRID) && I->split_min_quota != 0u && !(I->variant & 4096);
             if (split) { per_share_cap = per_share + SPLIT_EXTRA_PER_SHARE; grid = 8 * per_share_cap; }
@@ -582,17 +591,14 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             else if ((flags & F_GRID) && S.sig_age < 2) sched_rebuild = true;
             if (S.sig_age < 255) S.sig_age++;
         }
-    } else {
-        grid = (P.n_items + TRACE_BLOCK - 1) / TRACE_BLOCK;
     }
-    if ((flags & F_DEEP) && !I->strict && (uint64_t)(P.tiled ? base_grid : grid) >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
     /* deep launches: the scratch part of the DFS stack is sized for the launch's depth (7 / 15 / 31 parents) */
     if ((flags & F_DEEP) && !(flags & F_COUNT) && !(I->variant & 2048)) flags |= I->depth <= 8 ? F_D8 : (I->depth <= 16 ? F_D16 : 0);
     if (tail_wanted) {
         /* node storage of the tree-parallel tail: (27 or 29 + weights per light x lights) words per node, the parked lane state and the
          * replay's saved sums (whitted_tpt.inc); TPT_SLOTS_PER_XCC slots per XCD, taken and handed back by the waves themselves */
         const uint64_t per_node = (I->strict ? 29u : 27u) + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
-        const uint64_t fixed = 25u * 64u + (uint64_t)I->depth * 3u * 64u;
+        const uint64_t fixed = (25u + 36u) * 64u + (uint64_t)I->depth * 3u * 64u;   /* parked registers and LDS stack levels, saved sums */
         const uint64_t nslots = 8u * (uint64_t)TPT_SLOTS_PER_XCC;
         uint64_t slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / nslots) & ~(uint64_t)63;
         uint64_t cap = slice > fixed ? ((slice - fixed) / per_node) & ~(uint64_t)63 : 0;   /* whole blocks of 64 nodes */
@@ -760,6 +766,7 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->tpt_min = (unsigned)env_int("CLWRAP_TPT_MIN", (int)TPT_MIN_PATHS);
     I->tpt_pool_mb = (unsigned)env_int("CLWRAP_TPT_POOL_MB", (int)TPT_POOL_MB);
     I->split_min_quota = (unsigned)env_int("CLWRAP_SPLIT_MIN_QUOTA", (int)SPLIT_MIN_QUOTA);
+    I->tpt_clock = env_int("CLWRAP_TPT_CLOCK", 0) ? 1 : 0;
 
     wrap->impl = I;
     wrap->kernels_num = (cl_uint)I->kernels.size();

@@ -50,6 +50,7 @@ typedef struct {
     uint32_t* tpt_pool;
     uint32_t* tpt_flags;
     uint32_t tpt_slice_words, tpt_cap, tpt_slots, tpt_max, tpt_min;
+    uint32_t tpt_clock;    /* DIAGNOSTIC: 1 = the tail books its phases' durations into counter words 10-25 (`counters` must be set) */
     uint32_t cost_sum;     /* 1: a tile's cost is the SUM over its lanes (and over the wavefronts that share the tile), added atomically to a zeroed tile_cost; 0: the maximum over its lanes, stored */
     int32_t depth;         /* reference MAX_DEPTH                                     */
     /* scene */

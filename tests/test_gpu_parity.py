@@ -761,6 +761,100 @@ def test_deep_refraction_trees_on_the_glass_field(R, oracle, tex, sky, strict):
             check_exact(outs[0], want, f"glass field depth {depth}")
 
 
+# ------------------------------------------------------------ the tree-parallel tail of deep launches (csrc/whitted_tpt.inc)
+TAIL_KEYS = ("segments", "shadow_rays", "light_probes", "sky_fetches", "texel_fetches", "pushes", "shadow_rays_traced")
+
+
+def _tail_frame(r, max_lanes, frames=3):
+    """One counted frame with the tail entered at <= max_lanes live lanes (0: variant 16, the per-lane loop runs to the end).  Frames before
+    it let the dispatch order follow the tiles' costs, so that heavy tiles are served by several wavefronts when the tail is on."""
+    r.w.set_tpt(max_lanes, 1 if max_lanes == 64 else -1, -1)
+    r.w.set_variant(16 if max_lanes == 0 else 0)
+    for _ in range(frames - 1):
+        r.render(readback=False)
+    r.w.enable_counters(1)
+    img = r.render()
+    c = r.w.read_counters()
+    r.w.enable_counters(0)
+    return img, c
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("case", ["render.map d15", "render.map d8", "glass field d8", "glass field d15"])
+def test_tree_parallel_tail_equals_the_per_lane_loop(R, oracle, demo_scene, tex, sky, strict, case):
+    """Deep launches finish their tiles in the tree-parallel tail: pending paths become a pool of nodes traced by the whole wave, depth-first
+    positions and xorshift states come from subtree sizes, the lights' factors are added in a per-pixel replay.  Whatever share of a frame goes
+    through it -- entered at <= 8 or <= 24 live lanes (lanes arrive with stacks of continuations), or from the first segment on (64:
+    EVERYTHING through the tail), heavy tiles split over several wavefronts or not (variant 4096) -- pixels and ray counters equal the
+    per-lane loop's (variant 16), in both builds; the strict frames equal the oracle's."""
+    from example_gui_opencl_raytracer_amd import scene
+    glass_cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    sc, w, h, depth, cam = {"render.map d15": (demo_scene, 320, 240, 15, CAM), "render.map d8": (demo_scene, 200, 152, 8, CAM),
+                            "glass field d8": (scene.dielectric_field_scene(8), 256, 256, 8, glass_cam),
+                            "glass field d15": (scene.dielectric_field_scene(4), 160, 160, 15, glass_cam)}[case]
+    r = R(sc, tex, sky, w, h, depth=depth, strict=strict)
+    r.look(**cam)
+    ref, cref = _tail_frame(r, 0)
+    assert cref["tpt_tiles"] == 0
+    for max_lanes in (8, 24, 64):
+        img, c = _tail_frame(r, max_lanes)
+        assert c["tpt_tiles"] > 0 and c["tpt_nodes"] > 0, "the tail did not run"
+        assert np.array_equal(img, ref), f"{case}: tail entered at <= {max_lanes} lanes: {int((img != ref).sum())} pixels differ from the per-lane loop"
+        assert all(c[k] == cref[k] for k in TAIL_KEYS), (max_lanes, {k: (c[k], cref[k]) for k in TAIL_KEYS})
+    r.w.set_variant(4096)                                   # heavy tiles not split
+    r.w.set_tpt(24, -1, -1)
+    for _ in range(2):
+        r.render(readback=False)
+    assert np.array_equal(r.render(), ref)
+    r.release()
+    if strict:
+        want, _, _ = oracle.render(oracle.camera(cam["origin"], cam["look"], cam.get("fov", 90.0), cam.get("focal", 1.0), w, h), sc, tex, sky, depth)
+        check_exact(ref, want, f"tail / per-lane loop vs oracle: {case}")
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_tree_parallel_tail_gives_up_cleanly_when_its_slot_is_full(R, tex, sky, strict):
+    """A pool so small that a slot holds 192 nodes: the trees of the glass field at depth 15 outgrow it, the tail gives up on those tiles --
+    before it has touched any lane state -- and the per-lane loop finishes them: same pixels, same counters, and both paths were taken."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.dielectric_field_scene(4)
+    cam = dict(origin=(3.5, 3.0, -6.0), look=(0.0, -2.5, 9.5), fov=90.0, focal=1.0)
+    r = R(sc, tex, sky, 160, 160, depth=15, strict=strict)
+    r.look(**cam)
+    ref, cref = _tail_frame(r, 0)
+    per_node = (29 + 4 * 3) if strict else (27 + 3)
+    words = (25 + 36) * 64 + 15 * 192 + per_node * 192 + 63
+    r.w.set_tpt(-1, -1, max(1, (words * 8192 * 4) >> 20))
+    for max_lanes in (24, 64):
+        img, c = _tail_frame(r, max_lanes)
+        assert c["tpt_gave_up"] > 0 and c["tpt_tiles"] > 0, c
+        assert np.array_equal(img, ref)
+        assert all(c[k] == cref[k] for k in TAIL_KEYS)
+    r.release()
+
+
+def test_tree_parallel_tail_with_many_lights_and_on_the_grid(R, oracle, tex, sky):
+    """The tail's node carries one weight per light (strict: four): seven lights (more than the replay preloads), and a 576-sphere scene
+    whose segments walk the uniform grid, at depth 8 -- strict == oracle with everything through the tail."""
+    from example_gui_opencl_raytracer_amd import scene
+    sc = scene.sphere_grid_scene(24, 24)
+    cam = dict(origin=(0.0, 6.0, -8.0), look=(0.0, -0.45, 1.0), fov=90.0, focal=1.0)
+    base = scene.render_map_scene()
+    lights = np.concatenate([base.lights, base.lights, base.lights[:1]])
+    for k in range(len(lights)):
+        lights["origin"][k, :3] += np.float32(0.37 * k)
+    many = scene.Scene(base.spheres, base.planes, lights)
+    for sc_, cam_, w, h in ((many, CAM, 160, 120), (sc, cam, 160, 96)):
+        want, _, _ = oracle.render(oracle.camera(cam_["origin"], cam_["look"], cam_.get("fov", 90.0), cam_.get("focal", 1.0), w, h), sc_, tex, sky, 8)
+        r = R(sc_, tex, sky, w, h, depth=8, strict=True)
+        r.look(**cam_)
+        for max_lanes in (16, 64):
+            img, c = _tail_frame(r, max_lanes)
+            assert c["tpt_tiles"] > 0
+            check_exact(img, want, f"tail, {len(sc_.lights)} lights, {len(sc_.spheres)} spheres, entered at <= {max_lanes}")
+        r.release()
+
+
 # ------------------------------------------------------------ the other BASELINE.json configurations at FULL size
 def test_full_size_c3_glass_field_against_the_oracle(R, oracle, tex):
     """Config C3: 4096x4096, depth 8, 64 dielectric spheres.  493 M rays: the oracle needs the GPU box's host cores."""

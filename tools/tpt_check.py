@@ -60,10 +60,14 @@ for cfg in which:
             img, c = frame(r, tpt)
             if ref is None: ref = img
             for _ in range(3): r.render(readback=False)
+            r.w.read_counters()                          # (clears the phase clock's words: CLWRAP_TPT_CLOCK=1 books them in every build)
             r.w.timing_reset(); r.w.set_async(1)
             nfr = 30 if cfg != "c3" else 8
             for _ in range(nfr): r.render(readback=False)
             r.w.sync(); n, ms = r.w.timing_get(1); r.w.set_async(0)
+            pc = r.w.read_counters()
+            if os.environ.get("CLWRAP_TPT_CLOCK"):
+                c = dict(c, tpt_phase_us=[round(x / nfr, 1) for x in pc["tpt_phase_us"]], tpt_phase_max_us=pc["tpt_phase_max_us"], tpt_longest_us=pc["tpt_longest_us"])
             print(json.dumps(dict(config=cfg, strict=strict, tpt_max=tpt, kernel_ms=round(ms / n, 4), same=bool(np.array_equal(img, ref)), tail_tiles=c["tpt_tiles"],
-                                  gave_up=c["tpt_gave_up"], nodes=c["tpt_nodes"], phase_us=c["tpt_phase_us"], batches=c["tpt_batches"], max_batches=c["tpt_max_batches"], max_nodes=c["tpt_max_nodes"], longest_us=c["tpt_longest_us"], lane_util=round(c["lane_iters"] / max(c["wave_iters_x64"], 1), 4))), flush=True)
+                                  gave_up=c["tpt_gave_up"], nodes=c["tpt_nodes"], phase_us=c["tpt_phase_us"], phase_max_us=c["tpt_phase_max_us"], batches=c["tpt_batches"], max_batches=c["tpt_max_batches"], max_nodes=c["tpt_max_nodes"], longest_us=c["tpt_longest_us"], lane_util=round(c["lane_iters"] / max(c["wave_iters_x64"], 1), 4))), flush=True)
         r.release()
