@@ -394,6 +394,33 @@ def main():
                           note="the bit-exact parity build (clw_ext_set_strict) on the same workload")
         sl.release()
 
+    # ---- the reference driver's OWN configuration (800x600, MAX_DEPTH 15: raypng.c:6-7, raytracing.cl:8): a deep launch, bound by the refraction
+    #      trees of a few tiles -- with the tree-parallel tail (csrc/whitted_tpt.inc) and, beside it, with the per-lane loop alone (variant 16)
+    ref_leg = None
+    if rank == 0 and world == 1 and not args.strict and not c5 and not args.no_strict_leg:
+        from example_gui_opencl_raytracer_amd.renderer import Renderer
+        r = Renderer(ctx.sc, ctx.tex, ctx.sky, 800, 600, depth=15, strict=False)
+        r.look(**pkg.CAMERA_RAYPNG)
+        ref_leg = dict(frame="800x600", depth=15)
+        for key, variant in (("ms_per_frame", 0), ("ms_per_frame_per_lane_loop_only", 16)):
+            r.w.set_variant(variant)
+            for _ in range(4):
+                r.render(readback=False)
+            if variant == 0:
+                r.w.enable_counters(1); r.render(readback=False); c = r.w.read_counters(); r.w.enable_counters(0)
+                ref_leg.update(rays=c["segments"] + c["shadow_rays"], tiles_finished_by_the_tail=c["tpt_tiles"], nodes_in_the_tail=c["tpt_nodes"])
+                for _ in range(2):
+                    r.render(readback=False)
+            r.w.timing_reset(); r.w.set_timing_every(1); r.w.set_async(1)
+            for _ in range(40):
+                r.render(readback=False)
+            r.w.sync(); nn, ms = r.w.timing_get(1); r.w.set_async(0)
+            ref_leg[key] = round(ms / max(nn, 1), 4)
+        ref_leg["value"] = round(ref_leg["rays"] / ref_leg["ms_per_frame"] / 1e3, 1)
+        ref_leg["unit"] = "Mrays/s"
+        ref_leg["frames_per_s"] = round(1e3 / ref_leg["ms_per_frame"], 1)
+        r.release()
+
     # ---- the other legs (fewer steps: they are reported, not the headline)
     for m in want:
         if m in legs:
@@ -452,6 +479,8 @@ def main():
             line["strict"] = strict_leg
         if moving:
             line["moving_camera"] = moving
+        if ref_leg:
+            line["reference_config"] = ref_leg
         if png:
             line["png"] = png
         vi, vt = (profiled("SQ_INSTS_VALU"), profiled("SQ_INSTS_VALU_TRANS_F32")) if single_c2 and not args.strict else (None, None)
