@@ -553,7 +553,14 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     /* big deep launches are throughput-bound: the high-occupancy flavour (96 VGPRs, five waves per SIMD) -- which does not carry the tail:
      * under that register cap the tail's passes spill, and its code cost the per-lane loop 6 % (4096^2 depth 8: 7.4 -> 7.9 ms) */
     if ((flags & F_DEEP) && !I->strict && (uint64_t)base_grid >= (uint64_t)I->occ_tiles_per_depth * (unsigned)I->depth && !(I->variant & 64)) flags |= F_OCC;
-    const bool tail_wanted = (flags & F_DEEP) && !(flags & F_OCC) && !(I->variant & 16) && I->tpt_max != 0u;
+    /* the tree-parallel tail (whitted_tpt.inc): (27 or 29 + weights per light x lights) words per node; the parked lane state and LDS stack levels
+     * and the replay's saved sums besides; TPT_SLOTS_PER_XCC slots per XCD, taken and handed back by the waves themselves */
+    const uint64_t tpt_per_node = (I->strict ? 29u : 27u) + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
+    const uint64_t tpt_fixed = (25u + 36u) * 64u + (uint64_t)I->depth * 3u * 64u;
+    const uint64_t tpt_nslots = 8u * (uint64_t)TPT_SLOTS_PER_XCC;
+    const uint64_t tpt_slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / tpt_nslots) & ~(uint64_t)63;
+    const uint64_t tpt_cap = std::min<uint64_t>(tpt_slice > tpt_fixed ? ((tpt_slice - tpt_fixed) / tpt_per_node) & ~(uint64_t)63 : 0, 64960u);   /* whole blocks of 64 nodes; node ids are 16 bits */
+    const bool tail_wanted = (flags & F_DEEP) && !(flags & F_OCC) && !(I->variant & 16) && I->tpt_max != 0u && tpt_cap >= TPT_MIN_CAP;
     bool split = false;
     if (P.tiled) {
         if (I->sched && !(I->variant & 4) && trows <= 0xFFFu && tpr <= 0xFFFu) {   /* the order packs (tile column | row << 12 | parts) */
@@ -595,14 +602,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
     /* deep launches: the scratch part of the DFS stack is sized for the launch's depth (7 / 15 / 31 parents) */
     if ((flags & F_DEEP) && !(flags & F_COUNT) && !(I->variant & 2048)) flags |= I->depth <= 8 ? F_D8 : (I->depth <= 16 ? F_D16 : 0);
     if (tail_wanted) {
-        /* node storage of the tree-parallel tail: (27 or 29 + weights per light x lights) words per node, the parked lane state and the
-         * replay's saved sums (whitted_tpt.inc); TPT_SLOTS_PER_XCC slots per XCD, taken and handed back by the waves themselves */
-        const uint64_t per_node = (I->strict ? 29u : 27u) + (I->strict ? 4u : 1u) * (uint64_t)P.nl;
-        const uint64_t fixed = (25u + 36u) * 64u + (uint64_t)I->depth * 3u * 64u;   /* parked registers and LDS stack levels, saved sums */
-        const uint64_t nslots = 8u * (uint64_t)TPT_SLOTS_PER_XCC;
-        uint64_t slice = std::min<uint64_t>(TPT_SLICE_WORDS_MAX, ((uint64_t)I->tpt_pool_mb << 18) / nslots) & ~(uint64_t)63;
-        uint64_t cap = slice > fixed ? ((slice - fixed) / per_node) & ~(uint64_t)63 : 0;   /* whole blocks of 64 nodes */
-        if (cap > 64960u) cap = 64960u;                /* node ids are 16 bits */
+        const uint64_t nslots = tpt_nslots, slice = tpt_slice, cap = tpt_cap;
         if (cap >= TPT_MIN_CAP) {
             const size_t need = (size_t)slice * 4u * nslots;
             if (I->tpt_pool_bytes != need) {
