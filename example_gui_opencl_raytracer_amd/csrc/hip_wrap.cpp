@@ -155,7 +155,7 @@ struct Impl {
     uint64_t scene_generation = 0;   /* bumped every time the prepared scene is rebuilt (device pointers can be reused) */
     uint32_t *d_grid_start = nullptr, *d_grid_items = nullptr, *d_grid_box = nullptr;
     float* d_grid_geom = nullptr;
-    wprep_grid grid{}; bool grid_ok = false; int use_grid = 1;
+    wprep_grid grid{}; bool grid_ok = false, grid_pair = false; int use_grid = 1;
     unsigned long long* d_counters = nullptr;
     /* cost-sorted tile dispatch: costs written by frame n order the tiles of frame n+1 */
     int sched = 1;
@@ -391,7 +391,18 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     I->grid_ok = false;
     if (ns > (uint32_t)env_int("CLWRAP_GRID_MIN", (int)GRID_MIN_SPHERES)) {   /* CLWRAP_GRID_MIN: tuning knob */
         const char* dens = getenv("CLWRAP_GRID_DENSITY");   /* tuning knob: average spheres per cell */
-        size_t pairs = wprep_grid_plan(hs, ns, dens ? (float)atof(dens) : 1.6f, &I->grid);
+        /* the two soft-shadow samples of a light share one walk (wt_grid_shadow_pair) when spheres are listed a light radius beyond their
+         * boxes -- worth it while that is a fraction of a cell (CLWRAP_GRID_PAIR=0: every shadow ray walks on its own) */
+        float maxr = 0.0f;
+        for (uint32_t l = 0; l < nl; l++) { float r; memcpy(&r, hl + 48 * (size_t)l + 16, 4); r = fabsf(r); if (!(r <= maxr)) maxr = r; }
+        const float density = dens ? (float)atof(dens) : 1.6f;
+        size_t pairs = 0;
+        I->grid_pair = false;
+        if (env_int("CLWRAP_GRID_PAIR", 1) && nl > 0 && maxr > 0.0f && std::isfinite(maxr)) {
+            pairs = wprep_grid_plan(hs, ns, density, maxr, &I->grid);
+            I->grid_pair = maxr <= 0.3f * std::min(I->grid.cell[0], std::min(I->grid.cell[1], I->grid.cell[2])) && pairs <= GRID_MAX_PAIRS;
+        }
+        if (!I->grid_pair) pairs = wprep_grid_plan(hs, ns, density, 0.0f, &I->grid);
         if (pairs <= GRID_MAX_PAIRS) {
             std::vector<uint32_t> st((size_t)I->grid.ncells + 1), it(pairs ? pairs : 1), bx(2 * (size_t)ns);
             wprep_grid_fill(hs, ns, &I->grid, st.data(), it.data(), bx.data());
@@ -446,6 +457,7 @@ void bind_scene(cl_wrap* w, Impl* I, cl_uint kid, whitted_params& P, int& flags,
     P.sky = (const uint32_t*)sky->dptr; P.sky_w = (int)sky->w; P.sky_h = (int)sky->h;
     if (I->grid_ok && I->use_grid && !(I->variant & 8)) {
         flags |= F_GRID;
+        P.grid_pair = I->grid_pair ? 1u : 0u;
         P.grid_start = I->d_grid_start; P.grid_items = I->d_grid_items; P.grid_box = I->d_grid_box; P.grid_geom = I->d_grid_geom;
         for (int a = 0; a < 3; a++) {
             P.grid_min[a] = I->grid.gmin[a]; P.grid_inv[a] = I->grid.inv[a]; P.grid_cell[a] = I->grid.cell[a]; P.grid_res[a] = I->grid.res[a];

@@ -122,7 +122,7 @@ static void sphere_cells(const uint8_t* s, const wprep_grid* g, int lo[3], int h
     for (int a = 0; a < 3; a++) {
         float c = ldf(s, 4 * (size_t)a);
         /* conservative: the box is widened by a margin far larger than the traversal's rounding error */
-        float pad = 1e-3f * g->cell[a] + 1e-5f * (fabsf(c) + r);
+        float pad = 1e-3f * g->cell[a] + 1e-5f * (fabsf(c) + r) + g->reg_pad;
         int l = (int)floorf((c - r - pad - g->gmin[a]) * g->inv[a]);
         int h = (int)floorf((c + r + pad - g->gmin[a]) * g->inv[a]);
         lo[a] = l < 0 ? 0 : (l >= g->res[a] ? g->res[a] - 1 : l);
@@ -130,7 +130,8 @@ static void sphere_cells(const uint8_t* s, const wprep_grid* g, int lo[3], int h
     }
 }
 
-size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep_grid* g) {
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, float reg_pad, wprep_grid* g) {
+    g->reg_pad = (reg_pad > 0.0f && isfinite(reg_pad)) ? reg_pad * 1.001f + 1e-6f : 0.0f;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = 0; i < ns; i++) {
         const uint8_t* s = spheres + 96 * (size_t)i;
@@ -149,7 +150,7 @@ size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep
          * coordinate): a flat field of spheres (C4: 100 x 0.6 x 100) must not get a slab of empty space above it that every rising
          * shadow ray then walks through, cell by cell, testing the spheres below it (the margin used to be 1 % of the LARGEST extent:
          * 1.0 above a layer 0.6 thick; 9.5 -> 5 cells per shadow ray at C4) */
-        float pad = 1e-2f * ext[a] + 2e-5f * fmaxf(fabsf(mn[a]), fabsf(mx[a])) + 1e-3f;
+        float pad = 1e-2f * ext[a] + 2e-5f * fmaxf(fabsf(mn[a]), fabsf(mx[a])) + 1e-3f + 1.01f * g->reg_pad;
         mn[a] -= pad; mx[a] += pad; ext[a] = mx[a] - mn[a];
         vol *= ext[a];
     }

@@ -23,8 +23,12 @@ typedef struct {
     float gmin[3], inv[3], cell[3];
     int32_t res[3];
     uint32_t ncells;
+    float reg_pad;      /* every sphere is listed in all cells its box, widened by this much, touches (and the bounds reach that far) */
 } wprep_grid;
-size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, wprep_grid* g);
+/* reg_pad > 0 (the largest light radius): the two soft-shadow samples of a light can then share ONE walk along the ray to the light's
+ * centre -- a sphere either sample meets lies within reg_pad of that ray, so a cell the walk visits lists it (whitted_trace.inc
+ * wt_grid_shadow_pair) */
+size_t wprep_grid_plan(const uint8_t* spheres, uint32_t ns, float density, float reg_pad, wprep_grid* g);
 void wprep_grid_fill(const uint8_t* spheres, uint32_t ns, const wprep_grid* g, uint32_t* start, uint32_t* items,
                      uint32_t* box);
 #ifdef __cplusplus

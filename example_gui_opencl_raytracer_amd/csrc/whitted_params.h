@@ -74,6 +74,7 @@ typedef struct {
     const uint32_t* grid_box;
     const float* grid_geom;   /* float4 per cell-list entry: geom[grid_items[k]], so a test costs one load, not two dependent ones */
     float grid_min[3], grid_inv[3], grid_cell[3];
+    uint32_t grid_pair;      /* 1: spheres are listed a light radius beyond their boxes: the two samples of a light share one walk (wt_grid_shadow_pair) */
     int32_t grid_res[3];
     /* images: RGBA8 layer stacks */
     const uint32_t* tex; int32_t tex_w, tex_h, tex_layers;
