@@ -1,5 +1,5 @@
 #!/bin/bash
-for lib in "" _prev "" _prev; do
+for lib in "" _sa "" _sa; do
   if [ -n "$lib" ]; then export CLWRAP_LIB=$PWD/example_gui_opencl_raytracer_amd/libopencl_wrap_hip$lib.so; else unset CLWRAP_LIB; fi
-  python3 tools/run_config.py c3 --frames 8 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('lib=$lib c3', d['kernel_ms'], d['Mrays_s'])"
+  echo "lib=$lib"; timeout -k 10 600 python tools/tpt_check.py time ref800,hd15,c3s 48 2>&1 | cut -c1-100
 done
