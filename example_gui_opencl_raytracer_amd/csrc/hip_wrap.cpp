@@ -197,6 +197,7 @@ struct Impl {
     unsigned occ_tiles_per_depth = OCC_TILES_PER_DEPTH;   /* CLWRAP_OCC_TILES_PER_DEPTH: tuning knob */
     /* the tree-parallel tail of deep launches (whitted_tpt.inc): one slice of node storage per workgroup of the launch */
     uint32_t* d_tpt_pool = nullptr; uint32_t* d_tpt_flags = nullptr; size_t tpt_pool_bytes = 0;
+    uint32_t* d_tpt_jump = nullptr;              /* 7 x 32 words: M^(2^i), M = one hit's worth of xorshift steps (xorshift_jump_matrices) */
     unsigned tpt_max = TPT_MAX_LANES, tpt_min = TPT_MIN_PATHS, tpt_pool_mb = TPT_POOL_MB;   /* CLWRAP_TPT_MAX / _MIN / _POOL_MB, clw_ext_set_tpt */
     int tpt_clock = 0;                                    /* CLWRAP_TPT_CLOCK=1: DIAGNOSTIC phase clock of the tail (counter words 10-25) */
     unsigned split_min_quota = SPLIT_MIN_QUOTA;           /* CLWRAP_SPLIT_MIN_QUOTA; 0 = heavy tiles are not split */
@@ -365,6 +366,20 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
+/* xorshift32 (primitives.cl:116-125) is linear over GF(2): a step is a 32x32 bit matrix T (column b = the step applied to 1 << b), the 4 nl numbers
+ * a shaded hit draws are M = T^(4 nl), and the state k hits on is M^k times the state now.  out[i] = M^(2^i), i = 0..6, as columns: the tail's xorshift
+ * pass (whitted_tpt.inc, pass C) jumps with them instead of stepping. */
+void xorshift_jump_matrices(uint32_t steps, uint32_t out[7][32]) {
+    auto apply = [](const uint32_t* A, uint32_t x) { uint32_t r = 0; for (int b = 0; b < 32; b++) if ((x >> b) & 1u) r ^= A[b]; return r; };
+    auto mul = [&](const uint32_t* A, const uint32_t* B, uint32_t* C) { uint32_t t[32]; for (int b = 0; b < 32; b++) t[b] = apply(A, B[b]); memcpy(C, t, sizeof t); };
+    uint32_t T[32], R[32], Bp[32];
+    for (int b = 0; b < 32; b++) { uint32_t x = 1u << b; x ^= x << 13; x ^= x >> 17; x ^= x << 5; T[b] = x; R[b] = 1u << b; }
+    memcpy(Bp, T, sizeof T);
+    for (uint32_t e = steps; e; e >>= 1) { if (e & 1u) mul(Bp, R, R); mul(Bp, Bp, Bp); }      /* R = T^steps */
+    memcpy(out[0], R, sizeof R);
+    for (int i = 1; i < 7; i++) mul(out[i - 1], out[i - 1], out[i]);
+}
+
 void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buffer* l, uint32_t nl) {
     if (I->d_geom && I->prep_s == s && I->prep_p == p && I->prep_l == l && I->prep_ns == ns &&
         I->prep_np == np && I->prep_nl == nl)
@@ -379,6 +394,12 @@ void prepare_scene(Impl* I, Buffer* s, uint32_t ns, Buffer* p, uint32_t np, Buff
     wprep_build(hs, ns, hp, np, hl, nl, geom.data(), ptex.data());
     wprep_build_lpt(hp, np, hl, nl, geom.data() + 4 * base_f4);
     I->have_lpt = lpt_f4 != 0;
+    {   /* the tail's xorshift jumps for this light count */
+        uint32_t jm[7][32];
+        xorshift_jump_matrices(4u * nl, jm);
+        if (!I->d_tpt_jump) HIP_OK(hipMalloc((void**)&I->d_tpt_jump, sizeof jm), "Couldn't allocate device memory");
+        HIP_OK(hipMemcpy(I->d_tpt_jump, jm, sizeof jm, hipMemcpyHostToDevice), "Couldn't transfer the data from host to the device");
+    }
     if (I->d_geom) { (void)hipFree(I->d_geom); I->d_geom = nullptr; }
     if (I->d_ptex) { (void)hipFree(I->d_ptex); I->d_ptex = nullptr; }
     HIP_OK(hipMalloc((void**)&I->d_geom, geom.size() * 4), "Couldn't allocate device memory");
@@ -633,7 +654,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             }
             if (I->tpt_pool_bytes) {
                 P.tpt_pool = I->d_tpt_pool; P.tpt_flags = I->d_tpt_flags; P.tpt_slice_words = (uint32_t)slice; P.tpt_cap = (uint32_t)cap;
-                P.tpt_slots = TPT_SLOTS_PER_XCC;
+                P.tpt_slots = TPT_SLOTS_PER_XCC; P.tpt_jump = I->d_tpt_jump;
                 P.tpt_max = std::min(I->tpt_max, 64u); P.tpt_min = I->tpt_min;
             }
         }
@@ -901,6 +922,7 @@ void cl_wrap_release(cl_wrap* wrap) {
     if (I->d_counters) (void)hipFree(I->d_counters);
     if (I->d_tpt_pool) (void)hipFree(I->d_tpt_pool);
     if (I->d_tpt_flags) (void)hipFree(I->d_tpt_flags);
+    if (I->d_tpt_jump) (void)hipFree(I->d_tpt_jump);
     for (uint32_t* q : {I->d_grid_start, I->d_grid_items, I->d_grid_box}) if (q) (void)hipFree(q);
     if (I->d_grid_geom) (void)hipFree(I->d_grid_geom);
     if (I->sched_stream) (void)hipStreamSynchronize(I->sched_stream);

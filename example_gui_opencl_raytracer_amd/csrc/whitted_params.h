@@ -49,6 +49,7 @@ typedef struct {
      * 1 = slot taken (tpt_cap 0 = no tail: the per-lane loop runs to the end) */
     uint32_t* tpt_pool;
     uint32_t* tpt_flags;
+    const uint32_t* tpt_jump;   /* [7][32]: the GF(2) matrices M^(2^i), M = the xorshift steps of one shaded hit (4 x lights), as columns */
     uint32_t tpt_slice_words, tpt_cap, tpt_slots, tpt_max, tpt_min;
     uint32_t tpt_clock;    /* DIAGNOSTIC: 1 = the tail books its phases' durations into counter words 10-25 (`counters` must be set) */
     uint32_t cost_sum;     /* 1: a tile's cost is the SUM over its lanes (and over the wavefronts that share the tile), added atomically to a zeroed tile_cost; 0: the maximum over its lanes, stored */
