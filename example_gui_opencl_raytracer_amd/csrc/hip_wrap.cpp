@@ -52,8 +52,8 @@ constexpr unsigned TPT_MAX_LANES = 48, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TP
 constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
 /* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
  * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its
- * fixed costs); the quota is the share's total cost over the wavefronts its CUs hold at a time */
-constexpr unsigned SPLIT_EXTRA_PER_SHARE = 1024, SPLIT_MIN_QUOTA = 3000, SPLIT_SLOTS = 384, SPLIT_SLOTS_OCC = 640;
+ * fixed costs: 800x600 depth 15 0.267 ms at 3 000, 0.208 at 750-1 500); the quota is the share's total cost over SPLIT_SLOTS wavefronts (four times as many: over-split, 1920x1080 depth 15 +25 %) */
+constexpr unsigned SPLIT_EXTRA_PER_SHARE = 1024, SPLIT_MIN_QUOTA = 1500, SPLIT_SLOTS = 384;
 constexpr size_t COUNTER_WORDS = CLW_NUM_COUNTERS + 16 * (size_t)CLW_STAMP_SHARDS;
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
@@ -200,6 +200,7 @@ struct Impl {
     uint32_t* d_tpt_jump = nullptr;              /* 7 x 32 words: M^(2^i), M = one hit's worth of xorshift steps (xorshift_jump_matrices) */
     unsigned tpt_max = TPT_MAX_LANES, tpt_min = TPT_MIN_PATHS, tpt_pool_mb = TPT_POOL_MB;   /* CLWRAP_TPT_MAX / _MIN / _POOL_MB, clw_ext_set_tpt */
     int tpt_clock = 0;                                    /* CLWRAP_TPT_CLOCK=1: DIAGNOSTIC phase clock of the tail (counter words 10-25) */
+    unsigned split_slots = SPLIT_SLOTS;                   /* CLWRAP_SPLIT_SLOTS: the quota is a share's total cost over this many wavefronts */
     unsigned split_min_quota = SPLIT_MIN_QUOTA;           /* CLWRAP_SPLIT_MIN_QUOTA; 0 = heavy tiles are not split */
     bool timing_on = false;                       /* switched on by the first clw_ext_timing_reset / set_timing_every */
     uint32_t timing_every = 1, timing_tick = 0;   /* events around every n-th launch only */
@@ -671,7 +672,7 @@ void run_raytracer(cl_wrap* w, Impl* I, cl_uint kid, size_t array_size, const St
             HIP_OK(hipEventRecord(S.traced, I->stream), "Couldn't run the kernel");
             HIP_OK(hipStreamWaitEvent(I->sched_stream, S.traced, 0), "Couldn't run the kernel");
             if (wt_fast_launch_sched(S.cost[wr], S.order[wr], tpr, trows, per_share, (flags & F_GRID) ? 1u : 0u, per_share_cap,
-                                     split ? ((flags & F_OCC) ? SPLIT_SLOTS_OCC : SPLIT_SLOTS) : 0u, I->split_min_quota, I->sched_stream) != hipSuccess)
+                                     split ? I->split_slots : 0u, I->split_min_quota, I->sched_stream) != hipSuccess)
                 die("Couldn't run the kernel");
             HIP_OK(hipEventRecord(S.built[wr], I->sched_stream), "Couldn't run the kernel");
             S.have[wr] = true; S.newest = wr; S.newest_frame = S.frame - 1;
@@ -800,6 +801,7 @@ void cl_wrap_init(cl_wrap* wrap, cl_device_type type, ...) {
     I->tpt_pool_mb = (unsigned)env_int("CLWRAP_TPT_POOL_MB", (int)TPT_POOL_MB);
     I->split_min_quota = (unsigned)env_int("CLWRAP_SPLIT_MIN_QUOTA", (int)SPLIT_MIN_QUOTA);
     I->tpt_clock = env_int("CLWRAP_TPT_CLOCK", 0) ? 1 : 0;
+    I->split_slots = (unsigned)std::max(1, env_int("CLWRAP_SPLIT_SLOTS", (int)SPLIT_SLOTS));
 
     wrap->impl = I;
     wrap->kernels_num = (cl_uint)I->kernels.size();
