@@ -52,8 +52,8 @@ constexpr unsigned TPT_MAX_LANES = 48, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TP
 constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
 /* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
  * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its
- * fixed costs: 800x600 depth 15 0.267 ms at 3 000, 0.208 at 750-1 500); the quota is the share's total cost over SPLIT_SLOTS wavefronts (four times as many: over-split, 1920x1080 depth 15 +25 %) */
-constexpr unsigned SPLIT_EXTRA_PER_SHARE = 1024, SPLIT_MIN_QUOTA = 1500, SPLIT_SLOTS = 384;
+ * fixed costs: 800x600 depth 15 0.267 ms at 3 000, 0.208 at 750-1 500); the quota is the share's total cost over SPLIT_SLOTS wavefronts (384 / 512 / 640: 1920x1080 depth 15 0.370 / 0.332 / 0.322 ms, glass field 2048^2 depth 8 3.19 / 2.95 / 3.33) */
+constexpr unsigned SPLIT_EXTRA_PER_SHARE = 1024, SPLIT_MIN_QUOTA = 1500, SPLIT_SLOTS = 512;
 constexpr size_t COUNTER_WORDS = CLW_NUM_COUNTERS + 16 * (size_t)CLW_STAMP_SHARDS;
 constexpr unsigned BLOCK = 256;       /* the reference's launch rounding unit: CL_KERNEL_WORK_GROUP_SIZE on AMD (opencl_wrap.c:359-374) */
 constexpr unsigned TRACE_BLOCK = 64;  /* = WT_BLOCK: one wavefront per workgroup */
