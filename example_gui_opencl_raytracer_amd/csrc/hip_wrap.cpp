@@ -48,7 +48,7 @@ constexpr unsigned OCC_TILES_PER_DEPTH = 9000;
 /* tree-parallel tail (whitted_tpt.inc): a deep launch enters it with at most TPT_MAX_LANES live lanes holding at least TPT_MIN_PATHS
  * pending paths; the pool holds TPT_SLOTS_PER_XCC slots per XCD (more than an XCD's CUs hold wavefronts) of at most TPT_SLICE_WORDS_MAX
  * words, TPT_POOL_MB in all (below TPT_MIN_CAP nodes per slot -- hundreds of lights -- the launch runs without the tail) */
-constexpr unsigned TPT_MAX_LANES = 48, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160, TPT_SLOTS_PER_XCC = 1024;
+constexpr unsigned TPT_MAX_LANES = 40, TPT_MIN_PATHS = 4, TPT_POOL_MB = 8192, TPT_MIN_CAP = 160, TPT_SLOTS_PER_XCC = 1024;
 constexpr uint64_t TPT_SLICE_WORDS_MAX = 1u << 18;
 /* heavy tiles of such a launch are served by up to 16 wavefronts each (wt_sched_build): up to SPLIT_EXTRA_PER_SHARE more dispatch entries
  * per XCD share; a tile is split while its parts stay above SPLIT_MIN_QUOTA cost units (a part enters the tail at once and pays its

@@ -170,7 +170,7 @@ void clw_ext_set_variant(cl_wrap* wrap, int variant);
  * alive and they hold at least `min_paths` pending paths (current segments + continuations on their stacks), the rest of the tile is
  * traced by the whole wavefront as one pool of segments kept in a slot of a device pool of `pool_mb` MiB (8 192 slots).
  * Same image whatever the settings (the per-lane loop and the tail do the same arithmetic and add in the same order); max_lanes 64 sends
- * everything through the tail, 0 switches it off; a negative argument keeps the current value.  Defaults 48 / 4 / 8192, or
+ * everything through the tail, 0 switches it off; a negative argument keeps the current value.  Defaults 40 / 4 / 8192, or
  * CLWRAP_TPT_MAX / CLWRAP_TPT_MIN / CLWRAP_TPT_POOL_MB.  Counting build: counter words 29 / 30 / 31 = tiles the tail gave up on (slice
  * full: finished by the per-lane loop) / tiles it finished / nodes it traced. */
 void clw_ext_set_tpt(cl_wrap* wrap, int max_lanes, int min_paths, int pool_mb);

@@ -1,4 +1,2 @@
 #!/bin/bash
-python3 tools/run_config.py c3 --frames 6 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('c3 default', d['kernel_ms'], d['lane_util'])"
-python3 tools/run_config.py c3 --frames 6 --variant 64 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('c3 low-occupancy flavour + tail', d['kernel_ms'], d['lane_util'], d['counters'].get('tpt_tiles'))"
-CLWRAP_TPT_MAX=24 python3 tools/run_config.py c3 --frames 6 --variant 64 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('c3 low-occ + tail<=24', d['kernel_ms'], d['lane_util'])"
+timeout -k 10 900 python tools/tpt_check.py time ref800,hd15,c3s 24,32,40,48,56 2>&1 | cut -c1-100
